@@ -1,0 +1,179 @@
+/*
+ * vkmr_hip.h -- C ABI of the MI355X (gfx950) Merkle-root engine.
+ *
+ * This is the drop-in boundary: everything the reference's host code asked of
+ * Vulkan for the map -> reduce -> combine hot path, as plain
+ * C entry points over hand-written HIP kernels.  No C++ types, no exceptions, no
+ * torch types.  Every function returns a vkmr_status (0 = ok, negative = error,
+ * VKMR_NOT_READY = 1 from vkmr_hip_event_query only) and writes results through
+ * out-pointers; vkmr_hip_last_error() gives the text of the last failure on the
+ * calling thread.
+ *
+ * Each entry point cites the reference interface it replaces (file:line relative
+ * to the reference tree).  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Threading: one host thread may drive any number of devices; every call that
+ * takes `dev` selects that device itself.  Calls on one instance are not
+ * re-entrant across threads (same as the reference, which is single-threaded).
+ *
+ * Ownership: buffers passed to an *_async call stay owned by the caller and must
+ * stay alive until an event recorded after the call on the same stream has
+ * completed (reference: a Batch is freed when its Mapping retires,
+ * src/vkmr/Mappings.cpp:328-329; a Slice when its Reduction retires,
+ * src/vkmr/Reductions.cpp:663).
+ */
+#ifndef VKMR_HIP_H
+#define VKMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKMR_API __attribute__((visibility("default")))
+
+/* ---- status ------------------------------------------------------------- */
+typedef int vkmr_status;
+#define VKMR_OK            0
+#define VKMR_NOT_READY     1   /* vkmr_hip_event_query: work still in flight (VK_NOT_READY) */
+#define VKMR_ERR_INVALID  (-1) /* bad argument (null pointer, count/height mismatch, ...)   */
+#define VKMR_ERR_NO_DEVICE (-2)
+#define VKMR_ERR_OOM      (-3) /* VK_ERROR_OUT_OF_DEVICE_MEMORY / _HOST_MEMORY              */
+#define VKMR_ERR_HIP      (-4) /* any other HIP runtime failure                              */
+
+/* ---- wire structs: identical layout to the reference's device structs ---- */
+
+/* One packed input string.  Replaces VkSha256Metadata, src/common/SHA-256defs.h:51-54:
+ * `start` is a 32-bit WORD index into the packed data buffer, `size` is in BYTES. */
+typedef struct vkmr_metadata { uint32_t start; uint32_t size; } vkmr_metadata;
+
+/* One digest cell.  Replaces VkSha256Result, src/common/SHA-256defs.h:47-49: eight
+ * words holding the VALUES H[0..7], so raw little-endian memory is byte-swapped per
+ * word relative to the canonical digest. */
+typedef struct vkmr_digest { uint32_t data[8]; } vkmr_digest;
+
+typedef struct vkmr_stream_s* vkmr_stream;   /* replaces VkQueue + VkCommandBuffer      */
+typedef struct vkmr_event_s*  vkmr_event;    /* replaces VkFence and the timestamp pair */
+
+/* ---- devices (replaces VkSha256D's enumeration, src/vkmr/SHA-256vk.cpp:38-171) ---- */
+VKMR_API vkmr_status vkmr_hip_device_count(int* count);
+/* Marketing name of device `dev` (VkPhysicalDeviceProperties::deviceName). */
+VKMR_API vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen);
+/* Free/total HBM in bytes (ComputeDevice::AvailableMemoryTypes budgets,
+ * src/vkmr/Devices.h:184-245; used for slice sizing, src/vkmr/Slices.h:421-454). */
+VKMR_API vkmr_status vkmr_hip_device_mem_info(int dev, size_t* free_bytes, size_t* total_bytes);
+/* Compute-unit count and wavefront width (64 on gfx950); the reference reads
+ * subgroupSize here, src/vkmr/Reductions.cpp:749-770. */
+VKMR_API vkmr_status vkmr_hip_device_geometry(int dev, int* compute_units, int* wavefront);
+
+/* ---- memory --------------------------------------------------------------- */
+/* Pinned, zero-filled host buffer for a Batch's data / metadata (Batch::Buffer,
+ * src/vkmr/Batches.cpp:196-237: host-visible + coherent, memset 0). */
+VKMR_API vkmr_status vkmr_hip_host_alloc(size_t bytes, void** out);
+VKMR_API vkmr_status vkmr_hip_host_free(void* p);
+/* Device-local buffer: a Slice of digests (Slices::New, src/vkmr/Slices.h:297-384)
+ * or the HBM landing zone of a batch. */
+VKMR_API vkmr_status vkmr_hip_device_alloc(int dev, size_t bytes, void** out);
+VKMR_API vkmr_status vkmr_hip_device_free(int dev, void* p);
+VKMR_API vkmr_status vkmr_hip_memset_async(int dev, vkmr_stream s, void* dst, int value, size_t bytes);
+VKMR_API vkmr_status vkmr_hip_memcpy_h2d_async(int dev, vkmr_stream s, void* dst_dev, const void* src_host, size_t bytes);
+/* Used for the 32-byte root read-back (vkCmdCopyBuffer slice[0] -> host buffer,
+ * src/vkmr/Reductions.cpp:537-540) and by tests to fetch digests. */
+VKMR_API vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- streams and events ---------------------------------------------------- */
+/* A stream orders the ops submitted to it (the compute->compute barriers of
+ * src/vkmr/Reductions.cpp:506-519 come for free).  ComputeDevice::Queue round-robin,
+ * src/vkmr/Devices.cpp:525-538. */
+VKMR_API vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out);
+VKMR_API vkmr_status vkmr_hip_stream_destroy(int dev, vkmr_stream s);
+VKMR_API vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s);
+VKMR_API vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out);
+VKMR_API vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e);
+VKMR_API vkmr_status vkmr_hip_event_record(int dev, vkmr_event e, vkmr_stream s);
+/* vkGetFenceStatus (src/vkmr/Mappings.cpp:322, Reductions.cpp:642): VKMR_OK or VKMR_NOT_READY. */
+VKMR_API vkmr_status vkmr_hip_event_query(int dev, vkmr_event e);
+/* vkWaitForFences (src/vkmr/Mappings.cpp:362, Reductions.cpp:686). */
+VKMR_API vkmr_status vkmr_hip_event_wait(int dev, vkmr_event e);
+/* Make stream `s` wait for `e` (cross-stream ordering; no Vulkan counterpart needed
+ * in the single-queue reference). */
+VKMR_API vkmr_status vkmr_hip_stream_wait_event(int dev, vkmr_stream s, vkmr_event e);
+/* QueryPoolTimer::ElapsedMillis, src/vkmr/QueryPoolTimers.cpp:52-93. */
+VKMR_API vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end, float* ms);
+
+/* ---- the hot path ---------------------------------------------------------- */
+
+/*
+ * MAP: digests[i] = SHA-256(SHA-256(string i)) for i in [0,count).
+ * Replaces Mapping::Dispatch + shader entry `_SHA_256_N_`
+ * (src/vkmr/Mappings.cpp:135-232, src/shaders/SHA-256.comp:177-304).
+ *   data_dev    packed words in HBM, layout of Batch::Push (src/vkmr/Batches.cpp:64-121)
+ *   data_words  number of valid 32-bit words in data_dev (bounds every load)
+ *   meta_dev    count entries; string i occupies bytes [4*start, 4*start+size)
+ *   out_dev     count digest cells (a sub-slice, src/vkmr/Slices.h:145-187)
+ * Deliberate differences from the shader: bounds test is `>=`
+ * (Q4), tail bytes of the last word are masked to `size` (Q3), the 64-bit length
+ * uses size>>29 for the high word.  size == 0 hashes the empty string.
+ */
+VKMR_API vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s,
+                                        const uint32_t* data_dev, uint64_t data_words,
+                                        const vkmr_metadata* meta_dev, uint32_t count,
+                                        vkmr_digest* out_dev);
+
+/*
+ * REDUCE: sub-tree root of `count` digests through exactly `height` levels of
+ * node = SHA-256d(left || right), an unpaired node being paired with itself at
+ * every level, including after the count has collapsed to one.
+ * Replaces Reduction::Apply + ReductionBySubgroup::GetCommandBuffer + shader entry
+ * `_SHA_256_2_BE_`/`_VKMR_BY_SUBGROUP_` (src/vkmr/Reductions.cpp:147-216, :433-547,
+ * src/shaders/SHA-256.comp:308-391).  The caller chooses `height` exactly as the
+ * reference chooses `applicable` (src/vkmr/Reductions.cpp:471): log2(capacity) for
+ * every slice when the stream spans several slices, ceil(log2(count)) (at least 1:
+ * a lone leaf is hashed with itself, the CPU backend's rule)
+ * for a single slice.  Requires ceil(count / 2^height) == 1.
+ *   digests_dev  count cells, read only (the reference reduces in place)
+ *   scratch_dev  vkmr_hip_reduce_scratch_bytes(count) bytes of device memory
+ *   root_dev     one cell in device memory receiving the root
+ */
+VKMR_API vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s,
+                                           const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
+                                           void* scratch_dev, vkmr_digest* root_dev);
+VKMR_API size_t vkmr_hip_reduce_scratch_bytes(uint64_t count);
+
+/*
+ * One tree level per launch, one lane per pair: the reference's non-subgroup
+ * reduction (BasicReduction, src/vkmr/Reductions.cpp:257-409; shader :393-434).
+ * Kept as an independent cross-check of vkmr_hip_reduce_async; same contract.
+ * scratch_dev needs vkmr_hip_reduce_levels_scratch_bytes(count).
+ */
+VKMR_API vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s,
+                                                  const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
+                                                  void* scratch_dev, vkmr_digest* root_dev);
+VKMR_API size_t vkmr_hip_reduce_levels_scratch_bytes(uint64_t count);
+
+/*
+ * COMBINE: duplicate-last Merkle root over n >= 1 slice roots given in slice order
+ * (host memory), always at least one level -- the rule of CpuSha256D::Root that
+ * the reference applies to the slice roots on the CPU (CpuSha256DforReductions,
+ * src/vkmr/Reductions.cpp:56-69, :703-712).  Runs on device `dev`.  For n == 1 the
+ * reference prints the slice root itself (src/vkmr/Reductions.cpp:692-701); callers
+ * do the same and do not call combine.
+ */
+VKMR_API vkmr_status vkmr_hip_combine(int dev, const vkmr_digest* roots_host, uint32_t n, vkmr_digest* out_host);
+
+/* Canonical lower-case hex of a digest cell (hash_to_string + print_bytes,
+ * src/vkmr/SHA-256plus.cpp:453-469, src/vkmr/Debug.cpp:38-46).  hex holds 65 bytes. */
+VKMR_API void vkmr_hip_digest_hex(const vkmr_digest* d, char* hex);
+
+/* ---- diagnostics ----------------------------------------------------------- */
+VKMR_API const char* vkmr_hip_last_error(void);
+/* Name of the kernel variant a call would launch, for bench/profile bookkeeping. */
+VKMR_API const char* vkmr_hip_kernel_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKMR_HIP_H */

@@ -1,0 +1,180 @@
+"""GPU parity: the HIP path, called through the C ABI, against the oracle and the
+golden vectors.  Bit-exact (integer work).  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import golden_pattern
+
+pytestmark = pytest.mark.gpu
+
+
+def batch_of(strings):
+    import vk_merkle_roots_amd as vk
+    meta = np.zeros((len(strings), 2), dtype=np.uint32)
+    words = []
+    w = 0
+    for i, s in enumerate(strings):
+        meta[i] = (w, len(s))
+        nw = (len(s) + 3) // 4
+        words.append(s + b"\0" * (4 * nw - len(s)))
+        w += nw
+    data = np.frombuffer(b"".join(words), dtype=np.uint32).copy() if w else np.zeros(0, np.uint32)
+    return vk.PackedBatch(data, meta, w, sum(len(s) for s in strings))
+
+
+# ---- map ------------------------------------------------------------------------
+
+def test_map_golden_leaves(gpu, oracle, golden):
+    msgs = [golden_pattern(v["len"], v["salt"]) for v in golden["leaves"]]
+    got = gpu.leaf_digests(batch_of(msgs))
+    for v, row in zip(golden["leaves"], got):
+        assert oracle.hex(row) == v["sha256d"], v["len"]
+
+
+def test_map_every_length_0_to_300(gpu, oracle):
+    msgs = [golden_pattern(n, 5 + n) for n in range(0, 301)]
+    b = batch_of(msgs)
+    got = gpu.leaf_digests(b)
+    want = oracle.leaves_packed(b.data, b.meta)
+    assert (got == want).all()
+
+
+def test_map_masks_stale_tail_bytes(gpu, oracle):
+    """bytes after `size` in the last word must not reach the hash."""
+    msgs = [golden_pattern(n, n) for n in (1, 2, 3, 5, 6, 7, 57, 62, 63, 121)]
+    b = batch_of(msgs)
+    dirty = b.data.copy()
+    raw = dirty.view(np.uint8)
+    for st, sz in b.meta:
+        for k in range(int(sz), 4 * ((int(sz) + 3) // 4)):
+            raw[4 * int(st) + k] = 0xEE
+    import vk_merkle_roots_amd as vk
+    got = gpu.leaf_digests(vk.PackedBatch(dirty, b.meta, b.words, b.nbytes))
+    want = oracle.leaves_packed(b.data, b.meta)
+    assert (got == want).all()
+
+
+def test_map_last_thread_is_bounded(gpu, oracle):
+    """a count that is not a multiple of the workgroup must not write past it."""
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(21, 1000, 127)
+    d_data, d_meta = gpu.upload(b.data), gpu.upload(b.meta)
+    sentinel = np.full((1024, 8), 0xA5A5A5A5, dtype=np.uint32)
+    d_out = gpu.upload(sentinel)
+    gpu.map_async(d_data, b.words, d_meta, 1000, d_out)
+    out = gpu.download(d_out, 1024 * 32).reshape(-1, 8)
+    assert (out[:1000] == oracle.leaves_packed(b.data, b.meta)).all()
+    assert (out[1000:] == 0xA5A5A5A5).all()
+
+
+@pytest.mark.parametrize("seed,count,maxlen", [(1712489279, 1024, 127), (7, 1000, 300), (42, 4096, 4096), (3, 50000, 127),
+                                               (4, 3000, 2), (5, 777, 65), (6, 2000, 1024)])
+def test_map_rndm_batches(gpu, oracle, seed, count, maxlen):
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(seed, count, maxlen)
+    got = gpu.leaf_digests(b)
+    want = oracle.leaves_packed(b.data, b.meta, threads=8)
+    assert (got == want).all()
+
+
+def test_map_into_sub_slice_offsets(gpu, oracle):
+    """Two batches mapped into one slice at different offsets (Slice::Sub, reference Slices.h:145-187)."""
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(8, 3000, 127)
+    first, second = b.slice(0, 1234), b.slice(1234, 3000)
+    d_out = gpu.alloc(32 * 3000)
+    for part, off in ((first, 0), (second, 1234)):
+        d_data, d_meta = gpu.upload(part.data), gpu.upload(part.meta)
+        gpu.map_async(d_data, part.words, d_meta, part.count, d_out, out_offset_digests=off)
+        gpu.sync()
+    out = gpu.download(d_out, 32 * 3000).reshape(-1, 8)
+    assert (out == oracle.leaves_packed(b.data, b.meta)).all()
+
+
+# ---- reduce ----------------------------------------------------------------------
+
+COUNTS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 130, 255, 256, 257, 1000, 1023,
+          1024, 1025, 2047, 2048, 2049, 2050, 4095, 4097, 5000, 8191, 8193, 65535, 65537, 100000, 262143, 524288,
+          524289, 600001]
+
+
+@pytest.mark.parametrize("variant", ["wave", "levels"])
+def test_reduce_counts(gpu, oracle, variant):
+    rng = np.random.default_rng(1)
+    for n in COUNTS:
+        leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+        got = gpu.reduce_digests(leaves, levels_variant=(variant == "levels"))
+        assert (got == oracle.root(leaves, threads=8)).all(), (variant, n)
+
+
+@pytest.mark.parametrize("variant", ["wave", "levels"])
+def test_reduce_to_capacity_height(gpu, oracle, variant):
+    """A short last slice is reduced to the full slice height with self-pairing
+    (reference Reductions.cpp:471, README.md:94)."""
+    rng = np.random.default_rng(2)
+    for n, h in [(1, 1), (1, 5), (1, 23), (2, 4), (3, 10), (5, 3), (100, 12), (129, 23), (2049, 13), (2049, 20),
+                 (5000, 23), (70000, 17), (70000, 23), (300000, 20)]:
+        leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+        got = gpu.reduce_digests(leaves, height=h, levels_variant=(variant == "levels"))
+        assert (got == oracle.reduce_height(leaves, h)).all(), (variant, n, h)
+
+
+def test_reduce_does_not_modify_the_slice(gpu):
+    rng = np.random.default_rng(3)
+    leaves = rng.integers(0, 2**32, size=(10000, 8), dtype=np.uint32)
+    d_in = gpu.upload(leaves)
+    d_scratch = gpu.reduce_scratch(10000)
+    d_root = gpu.alloc(32)
+    gpu.reduce_async(d_in, 10000, 14, d_scratch, d_root)
+    assert (gpu.download(d_in, 32 * 10000).reshape(-1, 8) == leaves).all()
+
+
+def test_reduce_rejects_bad_height(gpu):
+    import vk_merkle_roots_amd as vk
+    d = gpu.alloc(32 * 8)
+    with pytest.raises(vk.VkmrError):
+        gpu.reduce_async(d, 8, 2, d, d)
+
+
+def test_combine_matches_cpu_rule(gpu, oracle):
+    rng = np.random.default_rng(4)
+    for n in [1, 2, 3, 8, 9, 100]:
+        roots = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+        assert (gpu.combine(roots) == oracle.root(roots)).all(), n
+
+
+# ---- whole path --------------------------------------------------------------------
+
+def test_golden_roots(gpu, golden):
+    import vk_merkle_roots_amd as vk
+    for name, s in golden["streams"].items():
+        if "stream_hex" in s:
+            b = vk.pack_lines(bytes.fromhex(s["stream_hex"]))
+        elif s.get("generator", "").startswith("rndm"):
+            a = s["generator"].split()
+            b = vk.rndm_packed(int(a[1]), int(a[2]), int(a[3]))
+        else:
+            alpha = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
+            b = vk.pack_lines("".join("%02d%s\n" % (i, alpha) for i in range(16)).encode())
+        assert (b.count, b.nbytes) == (s["items"], s["bytes"]), name
+        assert vk.merkle_root_packed(gpu, b) == s["root"], name
+
+
+@pytest.mark.parametrize("cap,batch", [(1 << 10, 700), (1 << 12, 5000), (1 << 16, 1 << 16), (1 << 17, 30000)])
+def test_multi_slice_equals_single_tree(gpu, golden, cap, batch):
+    """Config 2 stream cut into slices/batches of several sizes: always the golden root
+    (SURVEY.md 8a Q6)."""
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(42, 1 << 17, 127)
+    whole = vk.merkle_root_packed(gpu, b)
+    assert vk.merkle_root_packed(gpu, b, slice_capacity=cap, batch_strings=batch) == whole
+    assert vk.merkle_root_packed(gpu, b, slice_capacity=cap, batch_strings=batch, levels_variant=True) == whole
+
+
+def test_ragged_multi_slice(gpu, oracle):
+    import vk_merkle_roots_amd as vk
+    for n in (1, 2, 1023, 1025, 3000, 4097, 10000):
+        b = vk.rndm_packed(100 + n, n, 127)
+        want = oracle.hex(oracle.root(oracle.leaves_packed(b.data, b.meta)))
+        assert vk.merkle_root_packed(gpu, b) == want
+        assert vk.merkle_root_packed(gpu, b, slice_capacity=1024, batch_strings=300) == want

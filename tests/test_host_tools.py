@@ -1,0 +1,64 @@
+"""Host-side helpers: the restated glibc rand(), the rndm/strm tools, line packing."""
+import ctypes as C
+import ctypes.util
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def test_glibc_rand_restatement_matches_libc(native):
+    import vk_merkle_roots_amd as vk
+    libc = C.CDLL(ctypes.util.find_library("c"))
+    libc.rand.restype = C.c_int
+    h = vk.host_lib()
+    for seed in (1, 42, 1712489279, 0, 0xFFFFFFFF):
+        libc.srand(C.c_uint(seed))
+        want = np.array([libc.rand() for _ in range(5000)], dtype=np.int32)
+        got = np.zeros(5000, dtype=np.int32)
+        h.vkmr_host_rndm_rand(seed, got.ctypes.data, 5000)
+        assert (want == got).all(), seed
+
+
+def test_rndm_tool_stream_matches_reference_tool(native, golden):
+    rndm = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    g = golden["streams"]["G2_rndm_1712489279_1024_127"]
+    r = subprocess.run([rndm, "1712489279", "1024", "127"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert hashlib.sha256(r.stdout).hexdigest() == g["stream_sha256"]
+    assert b"Using seed: 1712489279" in r.stderr and b"Wrote 1024 string(s) in a total of 63646 byte(s)." in r.stderr
+
+
+def test_rndm_packed_equals_packing_the_stream(native):
+    import vk_merkle_roots_amd as vk
+    rndm = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    data = subprocess.run([rndm, "9", "500", "300"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    a = vk.pack_lines(data)
+    b = vk.rndm_packed(9, 500, 300)
+    assert a.count == b.count == 500 and a.words == b.words and a.nbytes == b.nbytes
+    assert (a.meta == b.meta).all() and (a.data == b.data).all()
+
+
+def test_pack_lines_rules(native):
+    import vk_merkle_roots_amd as vk
+    b = vk.pack_lines(b"\n\none\r\n\ntwo\n\n\nthree")
+    assert b.count == 3
+    assert b.meta.tolist() == [[0, 4], [1, 3], [2, 5]]
+    raw = b.data.tobytes()
+    assert raw[0:4] == b"one\r" and raw[4:7] == b"two" and raw[7] == 0 and raw[8:13] == b"three"
+    assert vk.pack_lines(b"").count == 0
+    assert vk.pack_lines(b"\n").count == 0
+    assert vk.pack_lines(b"x").meta.tolist() == [[0, 1]]
+
+
+def test_batch_slice_rebases_metadata(native):
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(3, 100, 50)
+    s = b.slice(10, 20)
+    assert s.count == 10 and s.meta[0, 0] == 0
+    for i in range(10):
+        st, sz = s.meta[i]
+        st0, sz0 = b.meta[10 + i]
+        assert sz == sz0
+        assert s.data[st: st + (sz + 3) // 4].tolist() == b.data[st0: st0 + (sz0 + 3) // 4].tolist()

@@ -1,0 +1,160 @@
+// sha256d_device.hpp -- SHA-256 building blocks for gfx950 (CDNA4) device code.
+//
+// Everything is 32-bit integer VALU work: rotates lower to v_alignbit_b32, Ch/Maj
+// and the three-way xors to v_bitop3_b32, the additions to v_add3_u32, byte swaps
+// to v_perm_b32.  Round constants are literals/SGPRs (uniform across the wave),
+// the message schedule is a 16-word ring in VGPRs; rounds are fully unrolled so
+// every ring index is static and constant blocks fold at compile time.
+//
+// Algorithm: FIPS 180-4 as used by the reference (src/common/SHA-256defs.h:16-26,
+// round body src/shaders/SHA-256.comp:120-152).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace vkmr_dev {
+
+struct Node { uint32_t w[8]; };   // word VALUES H[0..7] (VkSha256Result, SHA-256defs.h:47-49)
+
+__device__ constexpr uint32_t K256[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
+    0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,
+    0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,
+    0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+
+__device__ constexpr uint32_t IV256[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                                          0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+
+__device__ __forceinline__ constexpr uint32_t rotr(uint32_t x, unsigned n) { return (x >> n) | (x << (32u - n)); }
+
+// Three-input bitwise ops.  gfx950 has v_bitop3_b32 (any 3-input truth table in one
+// VALU op; table = f(0xF0, 0xCC, 0xAA)).  hipcc only finds part of these patterns
+// on its own, so they are spelled out; compile-time-constant operands keep the
+// plain C form so that constant blocks still fold completely.
+#define VKMR_ALL_CONST(a, b, c) (__builtin_constant_p(a) && __builtin_constant_p(b) && __builtin_constant_p(c))
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    if (VKMR_ALL_CONST(a, b, c)) return a ^ b ^ c;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+__device__ __forceinline__ uint32_t ch(uint32_t e, uint32_t f, uint32_t g)
+{
+    if (VKMR_ALL_CONST(e, f, g)) return (e & f) ^ (~e & g);
+    return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);
+}
+__device__ __forceinline__ uint32_t maj(uint32_t a, uint32_t b, uint32_t c)
+{
+    if (VKMR_ALL_CONST(a, b, c)) return (a & b) ^ (a & c) ^ (b & c);
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+}
+__device__ __forceinline__ uint32_t bsig0(uint32_t x) { return xor3(rotr(x, 2), rotr(x, 13), rotr(x, 22)); }
+__device__ __forceinline__ uint32_t bsig1(uint32_t x) { return xor3(rotr(x, 6), rotr(x, 11), rotr(x, 25)); }
+__device__ __forceinline__ uint32_t ssig0(uint32_t x) { return xor3(rotr(x, 7), rotr(x, 18), x >> 3); }
+__device__ __forceinline__ uint32_t ssig1(uint32_t x) { return xor3(rotr(x, 17), rotr(x, 19), x >> 10); }
+
+// One round with statically rotated register names: at round T the working
+// variable a lives in s[(0-T)&7], b in s[(1-T)&7], ... h in s[(7-T)&7].
+template <int T>
+__device__ __forceinline__ void round_fn(uint32_t (&s)[8], uint32_t kw)
+{
+    uint32_t& a = s[(0 - T) & 7];
+    uint32_t& b = s[(1 - T) & 7];
+    uint32_t& c = s[(2 - T) & 7];
+    uint32_t& d = s[(3 - T) & 7];
+    uint32_t& e = s[(4 - T) & 7];
+    uint32_t& f = s[(5 - T) & 7];
+    uint32_t& g = s[(6 - T) & 7];
+    uint32_t& h = s[(7 - T) & 7];
+    const uint32_t t1 = h + kw + bsig1(e) + ch(e, f, g);
+    d += t1;
+    h = t1 + bsig0(a) + maj(a, b, c);
+}
+
+// Round T including its message-schedule step (ring index T & 15 is static).
+template <int T>
+__device__ __forceinline__ void sched_round(uint32_t (&s)[8], uint32_t (&w)[16])
+{
+    constexpr int i = T & 15;
+    if (T >= 16) w[i] = w[i] + ssig0(w[(i + 1) & 15]) + w[(i + 9) & 15] + ssig1(w[(i + 14) & 15]);
+    round_fn<T>(s, K256[T] + w[i]);
+}
+
+template <int... T>
+__device__ __forceinline__ void all_rounds(uint32_t (&s)[8], uint32_t (&w)[16], std::integer_sequence<int, T...>)
+{
+    (sched_round<T>(s, w), ...);
+}
+
+// H <- H + compress(H, block).  `w` holds the 16 big-endian-valued message words
+// and is destroyed (it becomes the schedule ring).
+__device__ __forceinline__ void compress(uint32_t (&H)[8], uint32_t (&w)[16])
+{
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = H[i];
+    all_rounds(s, w, std::make_integer_sequence<int, 64>{});
+#pragma unroll
+    for (int i = 0; i < 8; ++i) H[i] += s[i];
+}
+
+// SHA-256 of a 32-byte digest given as word values (second hash of SHA-256d).
+// Restates sha256_be_1, src/shaders/SHA-256.comp:155-175: words 8..15 are the
+// constants 0x80000000, 0 x6, 256, so part of the schedule folds at compile time.
+__device__ __forceinline__ void hash_digest(const uint32_t (&in)[8], uint32_t (&out)[8])
+{
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = in[i];
+    w[8] = 0x80000000u;
+#pragma unroll
+    for (int i = 9; i < 15; ++i) w[i] = 0u;
+    w[15] = 256u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = IV256[i];
+    compress(out, w);
+}
+
+// Tree node = SHA-256(SHA-256(l || r)).  Restates sha256_be_2,
+// src/shaders/SHA-256.comp:308-323: block 1 = the two digests, block 2 = the
+// constant padding block (its whole schedule is a compile-time constant here),
+// then the digest hash.
+__device__ __forceinline__ void hash_pair(const uint32_t (&l)[8], const uint32_t (&r)[8], uint32_t (&out)[8])
+{
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w[i] = l[i]; w[8 + i] = r[i]; }
+    uint32_t H[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) H[i] = IV256[i];
+    compress(H, w);
+    w[0] = 0x80000000u;
+#pragma unroll
+    for (int i = 1; i < 15; ++i) w[i] = 0u;
+    w[15] = 512u;
+    compress(H, w);
+    hash_digest(H, out);
+}
+
+__device__ __forceinline__ Node load_node(const Node* p)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    Node n;
+    n.w[0] = lo.x; n.w[1] = lo.y; n.w[2] = lo.z; n.w[3] = lo.w;
+    n.w[4] = hi.x; n.w[5] = hi.y; n.w[6] = hi.z; n.w[7] = hi.w;
+    return n;
+}
+
+__device__ __forceinline__ void store_node(Node* p, const uint32_t (&h)[8])
+{
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    q[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+}  // namespace vkmr_dev

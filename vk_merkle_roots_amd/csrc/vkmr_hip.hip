@@ -1,0 +1,639 @@
+// vkmr_hip.hip -- HIP kernels (gfx950) and the C ABI of include/vkmr_hip.h.
+//
+// Kernels
+//   map_kernel          SHA-256d of every packed string        (replaces src/shaders/SHA-256.comp:177-304)
+//   reduce_pass_kernel  streaming sub-tree collapse per wave    (replaces SHA-256.comp:325-391)
+//   reduce_tail_kernel  top of a slice's tree, __shfl_down      (replaces SHA-256.comp:325-391, last passes)
+//   reduce_level_kernel one level per launch, cross-check       (replaces SHA-256.comp:393-434)
+//
+// Host side: plain launches on the caller's stream; no allocation, no sync inside
+// the *_async entry points.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vkmr_hip.h"
+#include "sha256d_device.hpp"
+
+using vkmr_dev::Node;
+
+// ============================================================================
+// MAP
+// ============================================================================
+
+// Builds message word `i` of block `b` for a string of `size` bytes whose packed
+// words begin at `src`: big-endian value of the input bytes, 0x80 terminator after
+// the last byte, zeros elsewhere.  Bytes past `size` in the last word are masked
+// (the shader does not, src/shaders/SHA-256.comp:248-250).
+__device__ __forceinline__ uint32_t message_word(const uint32_t* __restrict__ src, uint64_t words_left,
+                                                 uint32_t size, uint64_t off, uint32_t idx)
+{
+    uint32_t word = 0u;
+    if (off < size) {
+        uint32_t raw = (idx < words_left) ? src[idx] : 0u;
+        word = __builtin_bswap32(raw);
+        const uint32_t rem = size - (uint32_t)off;
+        if (rem < 4u) {
+            const uint32_t keep = 0xFFFFFFFFu << (8u * (4u - rem));
+            word = (word & keep) | (0x80u << (8u * (3u - rem)));
+        }
+    } else if (off == size) {
+        word = 0x80000000u;
+    }
+    return word;
+}
+
+// One lane per string.  Block count and padding follow cpu_sha256_n
+// (src/vkmr/SHA-256plus.cpp:133-226) / the shader (SHA-256.comp:187-289).
+__global__ __launch_bounds__(256) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
+                                                  const vkmr_metadata* __restrict__ meta, uint32_t count,
+                                                  Node* __restrict__ out)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;   // `>=`: SURVEY.md 8a Q4 (the shader tests `>`, SHA-256.comp:182)
+    const uint2 md = reinterpret_cast<const uint2*>(meta)[gid];
+    const uint32_t start = md.x, size = md.y;
+    const uint32_t nblocks = (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u;
+    const uint64_t words_left = (start < data_words) ? data_words - start : 0u;
+    const uint32_t* src = data + start;
+
+    uint32_t H[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) H[i] = vkmr_dev::IV256[i];
+
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        uint32_t w[16];
+        const uint64_t boff = (uint64_t)b << 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            w[i] = message_word(src, words_left, size, boff + 4u * i, (b << 4) + i);
+        if (b == nblocks - 1u) {
+            w[14] = size >> 29;   // high word of the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
+            w[15] = size << 3;
+        }
+        vkmr_dev::compress(H, w);
+    }
+    uint32_t o[8];
+    vkmr_dev::hash_digest(H, o);
+    vkmr_dev::store_node(out + gid, o);
+}
+
+// ============================================================================
+// REDUCE
+// ============================================================================
+
+#define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel
+#define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass
+#define VKMR_TAIL_MAX 2048  // the tail kernel takes at most this many nodes
+
+__device__ __forceinline__ uint64_t level_count(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
+
+// Each wave walks 2^m chunks of 128 consecutive nodes.  A chunk gives 64 level-1
+// nodes (one per lane).  Two such results of equal level merge into 64 nodes of
+// the next level: lanes 0..31 hash pairs of the earlier (pending) result, lanes
+// 32..63 pairs of the later one, so every step keeps all 64 lanes busy.  Pending
+// results wait in this wave's LDS region (64 nodes per level); the later half is
+// fetched from its lanes' registers with __shfl (ds_bpermute_b32).  After the last
+// chunk the wave holds 64 nodes of level m+1 and writes them out coalesced.
+// Pairing rule at every level: a node without a right sibling is paired with itself
+// (src/shaders/SHA-256.comp:337, :363).
+__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const Node* __restrict__ in, uint64_t n_in,
+                                                                           Node* __restrict__ out, uint32_t m)
+{
+    __shared__ uint4 pend_store[VKMR_PASS_WAVES * VKMR_PASS_MAXM * 64 * 2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t gwave = (uint64_t)blockIdx.x * VKMR_PASS_WAVES + wave;
+    const uint64_t base0 = gwave * (128ull << m);
+    if (base0 >= n_in) return;   // wave-uniform; no workgroup barrier is used below
+    Node* pend = reinterpret_cast<Node*>(pend_store) + wave * (VKMR_PASS_MAXM * 64);
+
+    uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t chunks = 1u << m;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        uint32_t cc = c;
+        uint32_t k = 0;   // this step turns level-k nodes into level-(k+1) nodes
+        for (;;) {
+            // first input node covered by this step, and this lane's output index
+            const uint64_t first = base0 + 128ull * ((uint64_t)c + 1ull - (1ull << k));
+            if (first < n_in) {   // wave-uniform: otherwise nothing below is a real node
+                const uint64_t j = (first >> (k + 1)) + lane;
+                const uint64_t ck = level_count(n_in, k);
+                uint32_t l[8], r[8];
+                if (k == 0) {
+                    if (2 * j < ck) {
+                        const Node a = vkmr_dev::load_node(in + 2 * j);
+                        const Node b = (2 * j + 1 < ck) ? vkmr_dev::load_node(in + 2 * j + 1) : a;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { l[i] = a.w[i]; r[i] = b.w[i]; }
+                    }
+                } else {
+                    const uint32_t src = (2u * lane) & 63u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        l[i] = __shfl(X[i], src);
+                        r[i] = __shfl(X[i], src + 1u);
+                    }
+                    if (lane < 32u) {
+                        const Node a = pend[(k - 1) * 64 + 2 * lane];
+                        const Node b = pend[(k - 1) * 64 + 2 * lane + 1];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { l[i] = a.w[i]; r[i] = b.w[i]; }
+                    }
+                    if (2 * j + 1 >= ck) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) r[i] = l[i];
+                    }
+                }
+                if (2 * j < ck) vkmr_dev::hash_pair(l, r, X);
+            }
+            ++k;
+            if (!(cc & 1u)) break;
+            cc >>= 1;
+        }
+        if (c + 1u != chunks) {
+            Node t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t.w[i] = X[i];
+            pend[(k - 1) * 64 + lane] = t;
+        }
+    }
+    const uint64_t jo = (base0 >> (m + 1)) + lane;
+    if (jo < level_count(n_in, m + 1)) vkmr_dev::store_node(out + jo, X);
+}
+
+// Top of the tree: up to VKMR_TAIL_MAX nodes, exactly `levels` levels, one
+// workgroup.  Level 1 comes from a coalesced pair load; the next six levels stay
+// inside each 64-lane wavefront with __shfl_down, exactly the shape of the
+// reference's subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377); up to
+// sixteen wave results then meet in LDS and one wave finishes with __shfl_down.
+// Any levels left once a single node remains hash that node with itself
+// ("keep iterating", README.md:94).
+__device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint32_t idx0, uint32_t lane, uint64_t n_in,
+                                                 uint32_t& done, uint32_t levels, uint32_t steps)
+{
+    for (uint32_t t = 0; t < steps && done < levels; ++t) {
+        const uint64_t cnt = level_count(n_in, done);   // nodes alive at the current level
+        const uint64_t me = idx0 >> t;                   // this lane's node index at that level
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = __shfl_down(X[i], 1u << t);
+        if (me + 1 >= cnt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = X[i];
+        }
+        if ((lane & ((2u << t) - 1u)) == 0u && me < cnt) {
+            uint32_t o[8];
+            vkmr_dev::hash_pair(X, r, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) X[i] = o[i];
+        }
+        ++done;
+    }
+}
+
+__global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restrict__ in, uint32_t n_in, uint32_t levels,
+                                                           Node* __restrict__ root)
+{
+    __shared__ Node wave_out[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t done = 0;
+    if (levels == 0) {   // n_in == 1: the root is the node itself
+        if (tid == 0) *root = in[0];
+        return;
+    }
+    if (2 * tid < n_in) {
+        const Node a = vkmr_dev::load_node(in + 2 * tid);
+        const Node b = (2 * tid + 1 < n_in) ? vkmr_dev::load_node(in + 2 * tid + 1) : a;
+        vkmr_dev::hash_pair(a.w, b.w, X);
+    }
+    done = 1;
+    shuffle_collapse(X, tid, lane, n_in, done, levels, 6);
+    if (done < levels) {   // uniform across the workgroup
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wave_out[wave].w[i] = X[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (lane < 16u && lane < (blockDim.x >> 6)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) X[i] = wave_out[lane].w[i];
+            }
+            shuffle_collapse(X, lane, lane, n_in, done, levels, 4);
+            while (done < levels) {   // a single node left: pair it with itself
+                uint32_t o[8];
+                vkmr_dev::hash_pair(X, X, o);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) X[i] = o[i];
+                ++done;
+            }
+        }
+    }
+    if (tid == 0) vkmr_dev::store_node(root, X);
+}
+
+// One level, one lane per pair (reference's BasicReduction shader, SHA-256.comp:393-434,
+// with `>=` bounds and self-pairing instead of the duplicate-last buffer copy,
+// src/vkmr/Reductions.cpp:299-342).
+__global__ __launch_bounds__(256) void reduce_level_kernel(const Node* __restrict__ in, uint64_t n_in, Node* __restrict__ out)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * p >= n_in) return;
+    const Node a = vkmr_dev::load_node(in + 2 * p);
+    const Node b = (2 * p + 1 < n_in) ? vkmr_dev::load_node(in + 2 * p + 1) : a;
+    uint32_t o[8];
+    vkmr_dev::hash_pair(a.w, b.w, o);
+    vkmr_dev::store_node(out + p, o);
+}
+
+// ============================================================================
+// C ABI
+// ============================================================================
+
+static thread_local char g_err[512] = "";
+
+static vkmr_status fail(vkmr_status code, const char* what, hipError_t e = hipSuccess)
+{
+    if (e != hipSuccess)
+        snprintf(g_err, sizeof g_err, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    else
+        snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+
+static vkmr_status from_hip(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return VKMR_OK;
+    (void)hipGetLastError();   // clear the sticky error
+    if (e == hipErrorOutOfMemory) return fail(VKMR_ERR_OOM, what, e);
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return fail(VKMR_ERR_NO_DEVICE, what, e);
+    return fail(VKMR_ERR_HIP, what, e);
+}
+
+#define VKMR_TRY(expr)                                   \
+    do {                                                 \
+        vkmr_status st__ = from_hip((expr), #expr);      \
+        if (st__ != VKMR_OK) return st__;                \
+    } while (0)
+
+static inline hipStream_t S(vkmr_stream s) { return reinterpret_cast<hipStream_t>(s); }
+static inline hipEvent_t E(vkmr_event e) { return reinterpret_cast<hipEvent_t>(e); }
+
+extern "C" {
+
+const char* vkmr_hip_last_error(void) { return g_err; }
+
+const char* vkmr_hip_kernel_info(void)
+{
+    return "map=map_kernel(lane-per-string) reduce=reduce_pass_kernel(m<=4)+reduce_tail_kernel";
+}
+
+vkmr_status vkmr_hip_device_count(int* count)
+{
+    if (!count) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_count: null out pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {   // no driver / no GPU: zero devices, like an empty Vulkan enumeration
+        (void)hipGetLastError();
+        *count = 0;
+        fail(VKMR_OK, "hipGetDeviceCount", e);
+        return VKMR_OK;
+    }
+    *count = n;
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_name: null buffer");
+    hipDeviceProp_t p;
+    VKMR_TRY(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s", p.name);
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_device_mem_info(int dev, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_mem_info: null out pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_device_geometry(int dev, int* compute_units, int* wavefront)
+{
+    hipDeviceProp_t p;
+    VKMR_TRY(hipGetDeviceProperties(&p, dev));
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (wavefront) *wavefront = p.warpSize;
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_host_alloc: bad argument");
+    void* p = nullptr;
+    VKMR_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    memset(p, 0, bytes);
+    *out = p;
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_host_free(void* p)
+{
+    if (!p) return VKMR_OK;
+    VKMR_TRY(hipHostFree(p));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_device_alloc(int dev, size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_alloc: bad argument");
+    VKMR_TRY(hipSetDevice(dev));
+    void* p = nullptr;
+    VKMR_TRY(hipMalloc(&p, bytes));
+    *out = p;
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_device_free(int dev, void* p)
+{
+    if (!p) return VKMR_OK;
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipFree(p));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_memset_async(int dev, vkmr_stream s, void* dst, int value, size_t bytes)
+{
+    if (!dst) return fail(VKMR_ERR_INVALID, "vkmr_hip_memset_async: null pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipMemsetAsync(dst, value, bytes, S(s)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_memcpy_h2d_async(int dev, vkmr_stream s, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!dst_dev || !src_host) return fail(VKMR_ERR_INVALID, "vkmr_hip_memcpy_h2d_async: null pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(s)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (!dst_host || !src_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_memcpy_d2h_async: null pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(s)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
+{
+    if (!out) return fail(VKMR_ERR_INVALID, "vkmr_hip_stream_create: null out pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    hipStream_t s;
+    VKMR_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = reinterpret_cast<vkmr_stream>(s);
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_stream_destroy(int dev, vkmr_stream s)
+{
+    if (!s) return VKMR_OK;
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipStreamDestroy(S(s)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s)
+{
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipStreamSynchronize(S(s)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out)
+{
+    if (!out) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_create: null out pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    hipEvent_t e;
+    VKMR_TRY(hipEventCreate(&e));
+    *out = reinterpret_cast<vkmr_event>(e);
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e)
+{
+    if (!e) return VKMR_OK;
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipEventDestroy(E(e)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_event_record(int dev, vkmr_event e, vkmr_stream s)
+{
+    if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_record: null event");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipEventRecord(E(e), S(s)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_event_query(int dev, vkmr_event e)
+{
+    if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_query: null event");
+    VKMR_TRY(hipSetDevice(dev));
+    hipError_t r = hipEventQuery(E(e));
+    if (r == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return VKMR_NOT_READY;
+    }
+    return from_hip(r, "hipEventQuery");
+}
+
+vkmr_status vkmr_hip_event_wait(int dev, vkmr_event e)
+{
+    if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_wait: null event");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipEventSynchronize(E(e)));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_stream_wait_event(int dev, vkmr_stream s, vkmr_event e)
+{
+    if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_stream_wait_event: null event");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipStreamWaitEvent(S(s), E(e), 0));
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end, float* ms)
+{
+    if (!begin || !end || !ms) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_elapsed_ms: null argument");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipEventElapsedTime(ms, E(begin), E(end)));
+    return VKMR_OK;
+}
+
+// ---- map ------------------------------------------------------------------------
+
+vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev, uint64_t data_words,
+                               const vkmr_metadata* meta_dev, uint32_t count, vkmr_digest* out_dev)
+{
+    if (count == 0) return VKMR_OK;
+    if (!meta_dev || !out_dev || (!data_dev && data_words != 0))
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    const uint32_t block = 256;
+    const uint32_t grid = (count + block - 1) / block;
+    hipLaunchKernelGGL(map_kernel, dim3(grid), dim3(block), 0, S(s), data_dev, data_words, meta_dev, count,
+                       reinterpret_cast<Node*>(out_dev));
+    VKMR_TRY(hipGetLastError());
+    return VKMR_OK;
+}
+
+// ---- reduce ---------------------------------------------------------------------
+
+static inline uint64_t ceil_shift(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
+
+// Levels a bulk pass collapses for n input nodes: the largest m+1 (m <= MAXM) that
+// still leaves enough wavefronts to fill 256 CUs.
+static uint32_t pick_m(uint64_t n)
+{
+    const uint64_t target_waves = 4096;
+    for (int m = VKMR_PASS_MAXM; m > 0; --m)
+        if (ceil_shift(n, 7 + m) >= target_waves) return (uint32_t)m;
+    return 0;
+}
+
+static bool height_ok(uint64_t count, uint32_t height)
+{
+    if (count == 0) return false;
+    if (height >= 64) return true;
+    return ceil_shift(count, height) == 1;
+}
+
+size_t vkmr_hip_reduce_scratch_bytes(uint64_t count)
+{
+    // ping-pong: outputs of pass 1 and pass 2 (later passes are smaller)
+    uint64_t n = count, total = 0;
+    for (int pass = 0; pass < 2 && n > VKMR_TAIL_MAX; ++pass) {
+        n = ceil_shift(n, pick_m(n) + 1);
+        total += n;
+    }
+    return (size_t)(total + 2) * sizeof(vkmr_digest);
+}
+
+vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint64_t count,
+                                  uint32_t height, void* scratch_dev, vkmr_digest* root_dev)
+{
+    if (!digests_dev || !root_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null pointer");
+    if (!height_ok(count, height))
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: height does not reduce count to one node");
+    if (count > VKMR_TAIL_MAX && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
+    VKMR_TRY(hipSetDevice(dev));
+
+    const Node* in = reinterpret_cast<const Node*>(digests_dev);
+    uint64_t n = count;
+    uint32_t left = height;
+    // scratch layout: [A: output of pass 1][B: output of pass 2]; later passes alternate
+    Node* bufA = reinterpret_cast<Node*>(scratch_dev);
+    Node* bufB = nullptr;
+    int pass = 0;
+    while (n > VKMR_TAIL_MAX) {
+        const uint32_t m = pick_m(n);
+        const uint64_t n_out = ceil_shift(n, m + 1);
+        Node* out;
+        if (pass == 0) {
+            out = bufA;
+            bufB = bufA + n_out;
+        } else {
+            out = (pass & 1) ? bufB : bufA;
+        }
+        const uint64_t waves = ceil_shift(n, 7 + m);
+        const uint64_t grid = (waves + VKMR_PASS_WAVES - 1) / VKMR_PASS_WAVES;
+        if (grid > 0x7fffffffull) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: slice too large");
+        hipLaunchKernelGGL(reduce_pass_kernel, dim3((uint32_t)grid), dim3(VKMR_PASS_WAVES * 64), 0, S(s), in, n, out, m);
+        VKMR_TRY(hipGetLastError());
+        in = out;
+        n = n_out;
+        left -= (m + 1);
+        ++pass;
+    }
+    uint32_t threads = (uint32_t)(((n + 1) / 2 + 63) / 64 * 64);
+    if (threads < 64) threads = 64;
+    hipLaunchKernelGGL(reduce_tail_kernel, dim3(1), dim3(threads), 0, S(s), in, (uint32_t)n, left,
+                       reinterpret_cast<Node*>(root_dev));
+    VKMR_TRY(hipGetLastError());
+    return VKMR_OK;
+}
+
+size_t vkmr_hip_reduce_levels_scratch_bytes(uint64_t count)
+{
+    return (size_t)(ceil_shift(count, 1) + ceil_shift(count, 2) + 2) * sizeof(vkmr_digest);
+}
+
+vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint64_t count,
+                                         uint32_t height, void* scratch_dev, vkmr_digest* root_dev)
+{
+    if (!digests_dev || !root_dev || !scratch_dev)
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: null pointer");
+    if (!height_ok(count, height))
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: height does not reduce count to one node");
+    VKMR_TRY(hipSetDevice(dev));
+    const Node* in = reinterpret_cast<const Node*>(digests_dev);
+    Node* bufA = reinterpret_cast<Node*>(scratch_dev);
+    Node* bufB = bufA + ceil_shift(count, 1);
+    uint64_t n = count;
+    for (uint32_t lv = 0; lv < height; ++lv) {
+        const uint64_t pairs = ceil_shift(n, 1);
+        Node* out = (lv + 1 == height) ? reinterpret_cast<Node*>(root_dev) : ((lv & 1) ? bufB : bufA);
+        const uint64_t grid = (pairs + 255) / 256;
+        hipLaunchKernelGGL(reduce_level_kernel, dim3((uint32_t)grid), dim3(256), 0, S(s), in, n, out);
+        VKMR_TRY(hipGetLastError());
+        in = out;
+        n = pairs;
+    }
+    if (height == 0) VKMR_TRY(hipMemcpyAsync(root_dev, digests_dev, sizeof(vkmr_digest), hipMemcpyDeviceToDevice, S(s)));
+    return VKMR_OK;
+}
+
+// ---- combine --------------------------------------------------------------------
+
+vkmr_status vkmr_hip_combine(int dev, const vkmr_digest* roots_host, uint32_t n, vkmr_digest* out_host)
+{
+    if (!roots_host || !out_host || n == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_combine: bad argument");
+    VKMR_TRY(hipSetDevice(dev));
+    uint32_t height = 1;   // at least one level: CpuSha256D::Root's do-while (SHA-256plus.cpp:515-547)
+    while (ceil_shift(n, height) > 1) ++height;
+    const size_t scratch = vkmr_hip_reduce_scratch_bytes(n);
+    char* buf = nullptr;
+    const size_t in_bytes = (size_t)n * sizeof(vkmr_digest);
+    VKMR_TRY(hipMalloc(reinterpret_cast<void**>(&buf), in_bytes + scratch + sizeof(vkmr_digest)));
+    vkmr_digest* d_in = reinterpret_cast<vkmr_digest*>(buf);
+    void* d_scratch = buf + in_bytes;
+    vkmr_digest* d_root = reinterpret_cast<vkmr_digest*>(buf + in_bytes + scratch);
+    vkmr_status st = from_hip(hipMemcpy(d_in, roots_host, in_bytes, hipMemcpyHostToDevice), "hipMemcpy(roots)");
+    if (st == VKMR_OK) st = vkmr_hip_reduce_async(dev, nullptr, d_in, n, height, d_scratch, d_root);
+    if (st == VKMR_OK) st = from_hip(hipMemcpy(out_host, d_root, sizeof(vkmr_digest), hipMemcpyDeviceToHost), "hipMemcpy(root)");
+    (void)hipFree(buf);
+    return st;
+}
+
+void vkmr_hip_digest_hex(const vkmr_digest* d, char* hex)
+{
+    static const char digits[] = "0123456789abcdef";
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 4; ++b) {
+            const unsigned v = (d->data[i] >> (24 - 8 * b)) & 0xffu;
+            hex[8 * i + 2 * b] = digits[v >> 4];
+            hex[8 * i + 2 * b + 1] = digits[v & 15u];
+        }
+    hex[64] = 0;
+}
+
+}  // extern "C"
