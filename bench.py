@@ -118,8 +118,10 @@ def main():
     batch = vk.rndm_packed(a.seed + rank, n, a.maxlen)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    d_data = dev.upload(batch.data)
-    d_meta = dev.upload(batch.meta)
+    d_batches = []          # one device-resident packed batch per map launch (own buffers, metadata rebased)
+    for b in range(nbatches):
+        sub = batch.slice(b * bstr, (b + 1) * bstr)
+        d_batches.append((dev.upload(sub.data), sub.words, dev.upload(sub.meta)))
     t_h2d = time.perf_counter() - t0
     input_bytes = batch.words * 4 + batch.count * 8
     d_digests = dev.alloc(32 * n)
@@ -130,7 +132,6 @@ def main():
     d_all_roots = dev.alloc(32 * nslices * world)
     d_final = dev.alloc(32)
     slice_height = a.slice_log2 if (nslices * world > 1) else tree_height(n)
-    words_per_batch = [int(batch.meta[(b + 1) * bstr - 1, 0]) + (int(batch.meta[(b + 1) * bstr - 1, 1]) + 3) // 4 for b in range(nbatches)]
 
     ev = [(dev.new_event(), dev.new_event()) for _ in range(2 * a.steps * (nbatches + 1))]
     used = []
@@ -147,7 +148,8 @@ def main():
             if timed:
                 e0, e1 = ev[len(used)]
                 dev.record(e0)
-            dev.map_async(d_data, words_per_batch[b], d_meta, bstr, d_digests, out_offset_digests=b * bstr, meta_offset=b * bstr)
+            d_data, words, d_meta = d_batches[b]
+            dev.map_async(d_data, words, d_meta, bstr, d_digests, out_offset_digests=b * bstr)
             if timed:
                 dev.record(e1)
                 used.append(("map", e0, e1))

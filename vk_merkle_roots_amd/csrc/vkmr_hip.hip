@@ -21,62 +21,176 @@ using vkmr_dev::Node;
 // ============================================================================
 // MAP
 // ============================================================================
+//
+// One workgroup (512 lanes = 8 wavefronts) maps one TILE of up to 1024 consecutive
+// strings:
+//   1. metadata -> LDS, block count per string, counting sort of the tile by block
+//      count (longest first) so that the 64 lanes of a wavefront run the same number
+//      of compressions -- one lane per string without the sort runs every wavefront
+//      at the pace of its longest string;
+//   2. the tile's packed bytes, contiguous in the batch (Batch::Push layout), are
+//      copied into LDS with coalesced 16-byte HBM loads (H5); a tile whose bytes do
+//      not fit (long strings) or whose metadata is not contiguous reads HBM per lane;
+//   3. wavefronts pull groups of 64 sorted strings and hash them: 16-word message
+//      blocks from LDS, byte swap, 0x80 / zero / bit-length padding by masks (no
+//      branches), 64 unrolled rounds with the schedule ring in VGPRs.
+// Digest i lands in out[i] whatever the processing order.
 
-// Builds message word `i` of block `b` for a string of `size` bytes whose packed
-// words begin at `src`: big-endian value of the input bytes, 0x80 terminator after
-// the last byte, zeros elsewhere.  Bytes past `size` in the last word are masked
-// (the shader does not, src/shaders/SHA-256.comp:248-250).
-__device__ __forceinline__ uint32_t message_word(const uint32_t* __restrict__ src, uint64_t words_left,
-                                                 uint32_t size, uint64_t off, uint32_t idx)
+#define VKMR_MAP_THREADS 512
+#define VKMR_MAP_MAX_TILE 1024
+#define VKMR_MAP_STAGE_WORDS 16384   // 64 KiB of packed input per tile
+#define VKMR_MAP_STAGE_PAD 32
+#define VKMR_MAP_BINS 64
+
+__device__ __forceinline__ uint32_t block_count(uint32_t size) { return (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u; }
+
+__global__ __launch_bounds__(VKMR_MAP_THREADS) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
+                                                               const vkmr_metadata* __restrict__ meta, uint32_t count,
+                                                               Node* __restrict__ out, uint32_t tile)
 {
-    uint32_t word = 0u;
-    if (off < size) {
-        uint32_t raw = (idx < words_left) ? src[idx] : 0u;
-        word = __builtin_bswap32(raw);
-        const uint32_t rem = size - (uint32_t)off;
-        if (rem < 4u) {
-            const uint32_t keep = 0xFFFFFFFFu << (8u * (4u - rem));
-            word = (word & keep) | (0x80u << (8u * (3u - rem)));
-        }
-    } else if (off == size) {
-        word = 0x80000000u;
-    }
-    return word;
-}
+    __shared__ uint4 s_stage4[(VKMR_MAP_STAGE_WORDS + VKMR_MAP_STAGE_PAD) / 4];
+    __shared__ uint2 s_meta[VKMR_MAP_MAX_TILE];
+    __shared__ uint16_t s_order[VKMR_MAP_MAX_TILE];
+    __shared__ uint32_t s_hist[VKMR_MAP_BINS];
+    __shared__ uint32_t s_binstart[VKMR_MAP_BINS];
+    __shared__ unsigned long long s_lo, s_hi;
+    __shared__ uint32_t s_next;
+    uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_stage4);
 
-// One lane per string.  Block count and padding follow cpu_sha256_n
-// (src/vkmr/SHA-256plus.cpp:133-226) / the shader (SHA-256.comp:187-289).
-__global__ __launch_bounds__(256) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
-                                                  const vkmr_metadata* __restrict__ meta, uint32_t count,
-                                                  Node* __restrict__ out)
-{
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= count) return;   // `>=`: SURVEY.md 8a Q4 (the shader tests `>`, SHA-256.comp:182)
-    const uint2 md = reinterpret_cast<const uint2*>(meta)[gid];
-    const uint32_t start = md.x, size = md.y;
-    const uint32_t nblocks = (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u;
-    const uint64_t words_left = (start < data_words) ? data_words - start : 0u;
-    const uint32_t* src = data + start;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint64_t tile_base = (uint64_t)blockIdx.x * tile;
+    if (tile_base >= count) return;
+    const uint32_t n_tile = (uint32_t)((count - tile_base < tile) ? count - tile_base : tile);
 
-    uint32_t H[8];
+    if (tid < VKMR_MAP_BINS) s_hist[tid] = 0u;
+    if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; s_next = 0u; }
+    __syncthreads();
+
+    // ---- 1. metadata, keys, extent of the tile's packed bytes -------------------------
+    constexpr int PER = VKMR_MAP_MAX_TILE / VKMR_MAP_THREADS;
+    uint32_t key[PER], rank[PER];
+    unsigned long long lo = ~0ull, hi = 0ull;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) H[i] = vkmr_dev::IV256[i];
-
-    for (uint32_t b = 0; b < nblocks; ++b) {
-        uint32_t w[16];
-        const uint64_t boff = (uint64_t)b << 6;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            w[i] = message_word(src, words_left, size, boff + 4u * i, (b << 4) + i);
-        if (b == nblocks - 1u) {
-            w[14] = size >> 29;   // high word of the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
-            w[15] = size << 3;
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = tid + k * VKMR_MAP_THREADS;
+        key[k] = 0u; rank[k] = 0u;
+        if (i < n_tile) {
+            const uint2 md = reinterpret_cast<const uint2*>(meta)[tile_base + i];
+            s_meta[i] = md;
+            const uint32_t nb = block_count(md.y);
+            key[k] = nb < VKMR_MAP_BINS ? nb : (VKMR_MAP_BINS - 1u);
+            rank[k] = atomicAdd(&s_hist[key[k]], 1u);
+            const unsigned long long b = md.x, e = b + (((unsigned long long)md.y + 3ull) >> 2);
+            lo = b < lo ? b : lo;
+            hi = e > hi ? e : hi;
         }
-        vkmr_dev::compress(H, w);
     }
-    uint32_t o[8];
-    vkmr_dev::hash_digest(H, o);
-    vkmr_dev::store_node(out + gid, o);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if (lane == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+
+    // ---- 2. bin starts, longest strings first -------------------------------------------
+    if (tid < VKMR_MAP_BINS) {
+        uint32_t acc = 0u;
+        for (uint32_t j = tid + 1u; j < VKMR_MAP_BINS; ++j) acc += s_hist[j];
+        s_binstart[tid] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = tid + k * VKMR_MAP_THREADS;
+        if (i < n_tile) s_order[s_binstart[key[k]] + rank[k]] = (uint16_t)i;
+    }
+
+    // ---- 3. stage the tile's packed words (coalesced) -------------------------------------
+    const unsigned long long t_lo = s_lo, t_hi = s_hi;
+    const unsigned long long a0 = t_lo & ~3ull;                 // 16-byte aligned start
+    const bool staged = (t_hi >= t_lo) && (t_hi - a0 <= VKMR_MAP_STAGE_WORDS) && (t_hi <= data_words) &&
+                        ((reinterpret_cast<uintptr_t>(data) & 15u) == 0u);
+    const uint32_t span = staged ? (uint32_t)(t_hi - a0) : 0u;  // words staged
+    if (staged) {
+        const uint4* src4 = reinterpret_cast<const uint4*>(data + a0);
+        for (uint32_t w = tid * 4u; w < span; w += VKMR_MAP_THREADS * 4u) {
+            uint4 v;
+            if (a0 + w + 4u <= data_words) {
+                v = src4[w >> 2];
+            } else {   // last, partial vector of the buffer
+                v.x = data[a0 + w];
+                v.y = (a0 + w + 1u < data_words) ? data[a0 + w + 1u] : 0u;
+                v.z = (a0 + w + 2u < data_words) ? data[a0 + w + 2u] : 0u;
+                v.w = 0u;
+            }
+            s_stage4[w >> 2] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. hash groups of 64 sorted strings ---------------------------------------------
+    const uint32_t ngroups = (n_tile + 63u) >> 6;
+    for (;;) {
+        uint32_t g = 0u;
+        if (lane == 0) g = atomicAdd(&s_next, 1u);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
+        const uint32_t pos = g * 64u + lane;
+        const bool has = pos < n_tile;
+        const uint32_t id = has ? s_order[pos] : 0u;
+        const uint2 md = s_meta[id];
+        const uint32_t start = md.x, size = has ? md.y : 0u;
+        const uint32_t nb = has ? block_count(size) : 0u;
+
+        uint32_t H[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) H[i] = vkmr_dev::IV256[i];
+
+        for (uint32_t b = 0; __any(b < nb); ++b) {
+            uint32_t w[16];
+            // raw words of this block (garbage beyond the string is masked below)
+            if (staged) {
+                uint32_t base = (uint32_t)(start - a0) + (b << 4);
+                base = base < span ? base : span;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = s_stage[base + i];
+            } else {
+                const uint64_t gbase = (uint64_t)start + ((uint64_t)b << 4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint64_t idx = gbase + i;
+                    w[i] = (idx < data_words) ? data[idx] : 0u;
+                }
+            }
+            // valid bytes of the string inside this block: 0..64
+            const uint64_t boff = (uint64_t)b << 6;
+            const uint32_t r = (boff >= size) ? 0u : ((size - boff >= 64u) ? 64u : (uint32_t)(size - boff));
+            const bool term_here = (boff <= size) && (size - boff < 64u);   // the 0x80 byte falls in this block
+            const uint32_t bw = term_here ? (r >> 2) : 16u;                 // word holding the terminator
+            const uint32_t kb = (r & 3u) << 3;
+            const uint32_t keep = kb ? (0xFFFFFFFFu << (32u - kb)) : 0u;
+            const uint32_t padbit = 0x80000000u >> kb;
+            const uint32_t full = r >> 2;                                   // whole data words
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t v = __builtin_bswap32(w[i]);
+                const uint32_t bnd = (v & keep) | padbit;
+                w[i] = ((uint32_t)i < full) ? v : (((uint32_t)i == bw) ? bnd : 0u);
+            }
+            if (b + 1u == nb) {   // last block carries the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
+                w[14] = size >> 29;
+                w[15] = size << 3;
+            }
+            if (b < nb) vkmr_dev::compress(H, w);
+        }
+        if (has) {
+            uint32_t o[8];
+            vkmr_dev::hash_digest(H, o);
+            vkmr_dev::store_node(out + tile_base + id, o);
+        }
+    }
 }
 
 // ============================================================================
@@ -289,7 +403,7 @@ const char* vkmr_hip_last_error(void) { return g_err; }
 
 const char* vkmr_hip_kernel_info(void)
 {
-    return "map=map_kernel(lane-per-string) reduce=reduce_pass_kernel(m<=4)+reduce_tail_kernel";
+    return "map=map_kernel(tile-sorted,LDS-staged) reduce=reduce_pass_kernel(m<=4)+reduce_tail_kernel";
 }
 
 vkmr_status vkmr_hip_device_count(int* count)
@@ -488,10 +602,17 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     if (!meta_dev || !out_dev || (!data_dev && data_words != 0))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
     VKMR_TRY(hipSetDevice(dev));
-    const uint32_t block = 256;
-    const uint32_t grid = (count + block - 1) / block;
-    hipLaunchKernelGGL(map_kernel, dim3(grid), dim3(block), 0, S(s), data_dev, data_words, meta_dev, count,
-                       reinterpret_cast<Node*>(out_dev));
+    // strings per tile: as many as are expected to fit the LDS staging area (64-string
+    // groups), at most 1024; long strings take full tiles and read HBM per lane
+    const uint64_t avg_words = (data_words + count - 1) / count;
+    uint32_t tile = VKMR_MAP_MAX_TILE;
+    if (avg_words > 0) {
+        const uint64_t fit = (uint64_t)(VKMR_MAP_STAGE_WORDS * 0.9) / avg_words;
+        if (fit >= 256 && fit < tile) tile = (uint32_t)(fit & ~63ull);
+    }
+    const uint32_t grid = (count + tile - 1) / tile;
+    hipLaunchKernelGGL(map_kernel, dim3(grid), dim3(VKMR_MAP_THREADS), 0, S(s), data_dev, data_words, meta_dev, count,
+                       reinterpret_cast<Node*>(out_dev), tile);
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
 }
