@@ -126,7 +126,8 @@ def main():
     input_bytes = batch.words * 4 + batch.count * 8
     d_digests = dev.alloc(32 * n)
     d_roots = dev.alloc(32 * max(nslices, 1))
-    scratch_bytes = (dev.lib.vkmr_hip_reduce_levels_scratch_bytes if a.levels_variant else dev.lib.vkmr_hip_reduce_scratch_bytes)(cap)
+    scratch_bytes = (dev.lib.vkmr_hip_reduce_levels_scratch_bytes(cap) if a.levels_variant
+                     else dev.lib.vkmr_hip_reduce_slices_scratch_bytes(cap, nslices))
     d_scratch = dev.alloc(scratch_bytes)
     d_top_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_scratch_bytes(max(nslices * world, 2)) + 64)
     d_all_roots = dev.alloc(32 * nslices * world)
@@ -157,10 +158,12 @@ def main():
         if timed:
             e0, e1 = ev[len(used)]
             dev.record(e0)
-        for s in range(nslices):
-            vk.check(((dev.lib.vkmr_hip_reduce_levels_async if a.levels_variant else dev.lib.vkmr_hip_reduce_async))(
-                dev.index, dev.stream, d_digests.at(32 * s * cap), cap, slice_height, d_scratch.ptr, d_roots.at(32 * s)),
-                "reduce")
+        if a.levels_variant:
+            for s in range(nslices):
+                vk.check(dev.lib.vkmr_hip_reduce_levels_async(dev.index, dev.stream, d_digests.at(32 * s * cap), cap, slice_height,
+                                                              d_scratch.ptr, d_roots.at(32 * s)), "reduce_levels")
+        else:
+            dev.reduce_slices_async(d_digests, nslices, cap, cap, slice_height, d_scratch, d_roots)
         if timed:
             dev.record(e1)
             used.append(("reduce", e0, e1))

@@ -144,6 +144,22 @@ VKMR_API vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s,
 VKMR_API size_t vkmr_hip_reduce_scratch_bytes(uint64_t count);
 
 /*
+ * REDUCE, several slices at once: `nslices` consecutive slices of `capacity` digests
+ * each (a power of two), the last holding `count_last` <= capacity, all reduced
+ * through `height` levels by the same launches; roots_dev[k] receives slice k's
+ * root.  This is Instance::Root's loop "for every remaining slice Reduce(...)"
+ * (src/vkmr/SHA-256vk.cpp:301-311) issued as one operation, so that the
+ * latency-bound tops of the sub-trees run side by side instead of one after the
+ * other.  Same per-slice contract as vkmr_hip_reduce_async.  scratch_dev needs
+ * vkmr_hip_reduce_slices_scratch_bytes(capacity, nslices).
+ */
+VKMR_API vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s,
+                                                  const vkmr_digest* digests_dev, uint32_t nslices,
+                                                  uint64_t capacity, uint64_t count_last, uint32_t height,
+                                                  void* scratch_dev, vkmr_digest* roots_dev);
+VKMR_API size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices);
+
+/*
  * One tree level per launch, one lane per pair: the reference's non-subgroup
  * reduction (BasicReduction, src/vkmr/Reductions.cpp:257-409; shader :393-434).
  * Kept as an independent cross-check of vkmr_hip_reduce_async; same contract.

@@ -136,6 +136,25 @@ def test_reduce_rejects_bad_height(gpu):
         gpu.reduce_async(d, 8, 2, d, d)
 
 
+def test_reduce_slices_batched(gpu, oracle):
+    """Several slices, short last one, reduced by one batched call (every slice to capacity height)."""
+    rng = np.random.default_rng(6)
+    for cap_log2, nslices, last in [(8, 3, 256), (8, 3, 1), (10, 5, 700), (13, 4, 8191), (18, 3, 100000), (19, 2, 524288),
+                                    (7, 9, 5), (15, 1, 20000)]:
+        cap = 1 << cap_log2
+        n = (nslices - 1) * cap + last
+        leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+        height = cap_log2 if nslices > 1 else max(1, int(last - 1).bit_length())
+        d_in = gpu.upload(leaves)
+        d_scratch = gpu.alloc(gpu.lib.vkmr_hip_reduce_slices_scratch_bytes(cap, nslices))
+        d_roots = gpu.alloc(32 * nslices)
+        gpu.reduce_slices_async(d_in, nslices, cap, last, height, d_scratch, d_roots)
+        got = gpu.download(d_roots, 32 * nslices).reshape(-1, 8)
+        for k in range(nslices):
+            want = oracle.reduce_height(leaves[k * cap: min(n, (k + 1) * cap)], height)
+            assert (got[k] == want).all(), (cap_log2, nslices, last, k)
+
+
 def test_combine_matches_cpu_rule(gpu, oracle):
     rng = np.random.default_rng(4)
     for n in [1, 2, 3, 8, 9, 100]:
@@ -169,6 +188,7 @@ def test_multi_slice_equals_single_tree(gpu, golden, cap, batch):
     whole = vk.merkle_root_packed(gpu, b)
     assert vk.merkle_root_packed(gpu, b, slice_capacity=cap, batch_strings=batch) == whole
     assert vk.merkle_root_packed(gpu, b, slice_capacity=cap, batch_strings=batch, levels_variant=True) == whole
+    assert vk.merkle_root_packed_batched(gpu, b, slice_capacity=cap, batch_strings=batch) == whole
 
 
 def test_ragged_multi_slice(gpu, oracle):

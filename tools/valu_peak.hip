@@ -36,6 +36,18 @@ __global__ __launch_bounds__(256) void spin(uint32_t* out, int iters)
                 if (KIND == 15) asm volatile("v_pk_add_u16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
                 if (KIND == 16) asm volatile("v_lshrrev_b64 %0, 7, %1" : "=v"(*(unsigned long long*)&a[i & 6]) : "v"(*(unsigned long long*)&a[(i + 2) & 6]));
                 if (KIND == 17) asm volatile("v_mov_b32_dpp %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 19) asm volatile("v_alignbit_b32 %0, %1, %1, 7" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 20) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]), "s"(iters));
+                if (KIND == 21) asm volatile("v_add3_u32 %0, %1, %1, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 22) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+                if (KIND == 24) asm volatile("v_lshlrev_b32 %0, 7, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 25) asm volatile("v_alignbit_b32 %0, %1, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(iters));
+                if (KIND == 26) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+                if (KIND == 27) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                if (KIND == 28) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(*(unsigned long long*)&a[i & 6]) : "v"(*(unsigned long long*)&a[(i + 2) & 6]), "v"(*(unsigned long long*)&a[(i + 4) & 6]));
+                if (KIND == 29) asm volatile("v_add_co_u32 %0, vcc, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc");
+                if (KIND == 30) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 31) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(unsigned long long*)&a[i & 6]) : "v"(*(unsigned long long*)&a[(i + 2) & 6]), "v"(*(unsigned long long*)&a[(i + 4) & 6]));
                 if (KIND == 18) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
             }
         }
@@ -89,6 +101,18 @@ int main()
         run<16>("v_lshrrev_b64", blocks, 4000, d);
         run<17>("v_mov_b32_dpp", blocks, 4000, d);
         run<18>("v_add_u32_sdwa", blocks, 4000, d);
+        run<19>("alignbit same-reg", blocks, 4000, d);
+        run<20>("add3 v,v,s", blocks, 4000, d);
+        run<21>("add3 same-reg", blocks, 4000, d);
+        run<22>("v_bfi_b32", blocks, 4000, d);
+        run<24>("v_lshlrev_b32", blocks, 4000, d);
+        run<25>("alignbit v,v,s", blocks, 4000, d);
+        run<26>("v_mad_u32_u24", blocks, 4000, d);
+        run<27>("v_mul_lo_u32", blocks, 4000, d);
+        run<28>("v_pk_mul_f32", blocks, 4000, d);
+        run<29>("v_add_co_u32", blocks, 4000, d);
+        run<30>("v_mov_b32", blocks, 4000, d);
+        run<31>("v_pk_add_f32", blocks, 4000, d);
     }
     for (int wavesPerSimd : {1, 2, 4, 8}) {
         int blocks = p.multiProcessorCount * wavesPerSimd;   // 256-thread blocks = 4 waves = 1 per SIMD

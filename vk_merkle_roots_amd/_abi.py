@@ -46,6 +46,9 @@ SIGNATURES = {
     "vkmr_hip_map_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vkmr_hip_reduce_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_reduce_scratch_bytes": (C.c_size_t, [C.c_uint64]),
+    "vkmr_hip_reduce_slices_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
+                                               C.c_void_p, C.c_void_p]),
+    "vkmr_hip_reduce_slices_scratch_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32]),
     "vkmr_hip_reduce_levels_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_reduce_levels_scratch_bytes": (C.c_size_t, [C.c_uint64]),
     "vkmr_hip_combine": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),

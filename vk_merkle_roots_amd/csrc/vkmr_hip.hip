@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/vkmr_hip.h"
 #include "sha256d_device.hpp"
@@ -22,7 +23,7 @@ using vkmr_dev::Node;
 // MAP
 // ============================================================================
 //
-// One workgroup (512 lanes = 8 wavefronts) maps one TILE of up to 1024 consecutive
+// One workgroup (256 lanes = 4 wavefronts) maps one TILE of up to 512 consecutive
 // strings:
 //   1. metadata -> LDS, block count per string, counting sort of the tile by block
 //      count (longest first) so that the 64 lanes of a wavefront run the same number
@@ -36,18 +37,18 @@ using vkmr_dev::Node;
 //      branches), 64 unrolled rounds with the schedule ring in VGPRs.
 // Digest i lands in out[i] whatever the processing order.
 
-#define VKMR_MAP_THREADS 512
-#define VKMR_MAP_MAX_TILE 1024
-#define VKMR_MAP_STAGE_WORDS 16384   // 64 KiB of packed input per tile
 #define VKMR_MAP_STAGE_PAD 32
 #define VKMR_MAP_BINS 64
 
 __device__ __forceinline__ uint32_t block_count(uint32_t size) { return (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u; }
 
-__global__ __launch_bounds__(VKMR_MAP_THREADS) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
-                                                               const vkmr_metadata* __restrict__ meta, uint32_t count,
-                                                               Node* __restrict__ out, uint32_t tile)
+// THREADS lanes per workgroup, tiles of at most MAX_TILE strings, STAGE_WORDS words of LDS staging.
+template <int THREADS, int MAX_TILE, int STAGE_WORDS>
+__global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
+                                                      const vkmr_metadata* __restrict__ meta, uint32_t count,
+                                                      Node* __restrict__ out, uint32_t tile)
 {
+    constexpr int VKMR_MAP_THREADS = THREADS, VKMR_MAP_MAX_TILE = MAX_TILE, VKMR_MAP_STAGE_WORDS = STAGE_WORDS;
     __shared__ uint4 s_stage4[(VKMR_MAP_STAGE_WORDS + VKMR_MAP_STAGE_PAD) / 4];
     __shared__ uint2 s_meta[VKMR_MAP_MAX_TILE];
     __shared__ uint16_t s_order[VKMR_MAP_MAX_TILE];
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(VKMR_MAP_THREADS) void map_kernel(const uint32_t* _
 
 #define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel
 #define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass
-#define VKMR_TAIL_MAX 2048  // the tail kernel takes at most this many nodes
 
 __device__ __forceinline__ uint64_t level_count(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
 
@@ -212,9 +212,19 @@ __device__ __forceinline__ uint64_t level_count(uint64_t n, unsigned k) { return
 // chunk the wave holds 64 nodes of level m+1 and writes them out coalesced.
 // Pairing rule at every level: a node without a right sibling is paired with itself
 // (src/shaders/SHA-256.comp:337, :363).
-__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const Node* __restrict__ in, uint64_t n_in,
-                                                                           Node* __restrict__ out, uint32_t m)
+// Several equal-capacity slices can be reduced by one launch: blockIdx.y picks the
+// slice (input `in_stride` nodes apart, output `out_stride` apart); the last slice
+// may hold fewer nodes (`n_last`) than the others (`n_full`).
+struct SliceGeom { uint64_t n_full, n_last, in_stride, out_stride; uint32_t nslices; };
+
+__device__ __forceinline__ uint64_t slice_count(const SliceGeom& g) { return (blockIdx.y + 1u == g.nslices) ? g.n_last : g.n_full; }
+
+__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const Node* __restrict__ in0, SliceGeom geom,
+                                                                           Node* __restrict__ out0, uint32_t m)
 {
+    const uint64_t n_in = slice_count(geom);
+    const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
+    Node* __restrict__ out = out0 + blockIdx.y * geom.out_stride;
     __shared__ uint4 pend_store[VKMR_PASS_WAVES * VKMR_PASS_MAXM * 64 * 2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
 // sixteen wave results then meet in LDS and one wave finishes with __shfl_down.
 // Any levels left once a single node remains hash that node with itself
 // ("keep iterating", README.md:94).
-__device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint32_t idx0, uint32_t lane, uint64_t n_in,
+__device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0, uint32_t lane, uint64_t n_in,
                                                  uint32_t& done, uint32_t levels, uint32_t steps)
 {
     for (uint32_t t = 0; t < steps && done < levels; ++t) {
@@ -307,9 +317,12 @@ __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint32_t idx0
     }
 }
 
-__global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restrict__ in, uint32_t n_in, uint32_t levels,
-                                                           Node* __restrict__ root)
+__global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                           Node* __restrict__ root0)
 {
+    const uint32_t n_in = (uint32_t)slice_count(geom);
+    const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
+    Node* __restrict__ root = root0 + blockIdx.y * geom.out_stride;
     __shared__ Node wave_out[16];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -348,6 +361,32 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restric
         }
     }
     if (tid == 0) vkmr_dev::store_node(root, X);
+}
+
+// Middle of the tree, where there are too few nodes to keep every SIMD busy: one
+// wavefront per workgroup (so the wavefronts spread over all CUs) collapses 128
+// nodes through `levels` (1..7) levels -- a coalesced pair load, then __shfl_down
+// steps as in the reference's subgroup shader.  Lane utilisation is poor by
+// construction here but these passes are latency-bound: what counts
+// is the ~9 us one wavefront needs per level, not the idle lanes.
+__global__ __launch_bounds__(64) void reduce_collapse_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                             Node* __restrict__ out0)
+{
+    const uint64_t n_in = slice_count(geom);
+    const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
+    Node* __restrict__ out = out0 + blockIdx.y * geom.out_stride;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;   // level-1 node of this lane
+    uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (2 * j < n_in) {
+        const Node a = vkmr_dev::load_node(in + 2 * j);
+        const Node b = (2 * j + 1 < n_in) ? vkmr_dev::load_node(in + 2 * j + 1) : a;
+        vkmr_dev::hash_pair(a.w, b.w, X);
+    }
+    uint32_t done = 1;
+    shuffle_collapse(X, j, lane, n_in, done, levels, 6);
+    const uint64_t jo = j >> (levels - 1u);
+    if ((lane & ((1u << (levels - 1u)) - 1u)) == 0u && jo < level_count(n_in, levels)) vkmr_dev::store_node(out + jo, X);
 }
 
 // One level, one lane per pair (reference's BasicReduction shader, SHA-256.comp:393-434,
@@ -403,7 +442,7 @@ const char* vkmr_hip_last_error(void) { return g_err; }
 
 const char* vkmr_hip_kernel_info(void)
 {
-    return "map=map_kernel(tile-sorted,LDS-staged) reduce=reduce_pass_kernel(m<=4)+reduce_tail_kernel";
+    return "map=map_kernel(tile-sorted,LDS-staged) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
 }
 
 vkmr_status vkmr_hip_device_count(int* count)
@@ -603,16 +642,26 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
         return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
     VKMR_TRY(hipSetDevice(dev));
     // strings per tile: as many as are expected to fit the LDS staging area (64-string
-    // groups), at most 1024; long strings take full tiles and read HBM per lane
+    // groups), at most MAX_TILE; long strings take full tiles and read HBM per lane
+    static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
-    uint32_t tile = VKMR_MAP_MAX_TILE;
-    if (avg_words > 0) {
-        const uint64_t fit = (uint64_t)(VKMR_MAP_STAGE_WORDS * 0.9) / avg_words;
-        if (fit >= 256 && fit < tile) tile = (uint32_t)(fit & ~63ull);
+    auto launch = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
+        uint32_t tile = max_tile;
+        if (avg_words > 0) {
+            const uint64_t fit = (uint64_t)(stage_words * 0.9) / avg_words;
+            if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
+        }
+        const uint32_t grid = (count + tile - 1) / tile;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count,
+                           reinterpret_cast<Node*>(out_dev), tile);
+    };
+    switch (variant) {   // VKMR_MAP_VARIANT selects an experimental geometry; 0 = the shipped one
+        case 1: launch(map_kernel<512, 1024, 16384>, 512, 1024, 16384); break;
+        case 2: launch(map_kernel<384, 768, 12288>, 384, 768, 12288); break;
+        case 3: launch(map_kernel<1024, 2048, 32768>, 1024, 2048, 32768); break;
+        case 4: launch(map_kernel<256, 1024, 16384>, 256, 1024, 16384); break;
+        default: launch(map_kernel<256, 512, 8192>, 256, 512, 8192); break;   // 4 workgroups/CU, 38 KiB LDS each
     }
-    const uint32_t grid = (count + tile - 1) / tile;
-    hipLaunchKernelGGL(map_kernel, dim3(grid), dim3(VKMR_MAP_THREADS), 0, S(s), data_dev, data_words, meta_dev, count,
-                       reinterpret_cast<Node*>(out_dev), tile);
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
 }
@@ -638,15 +687,83 @@ static bool height_ok(uint64_t count, uint32_t height)
     return ceil_shift(count, height) == 1;
 }
 
+// One step of the reduction schedule for n nodes with `left` levels to go:
+//   bulk     n/128 >= 2048 wavefronts: reduce_pass_kernel, m+1 levels, every lane busy
+//   collapse 128 < n: reduce_collapse_kernel, up to 7 levels, one wavefront per CU slot
+//   tail     n <= 128: reduce_tail_kernel, one wavefront, all remaining levels
+struct ReduceStep { int kind; uint32_t levels; uint64_t n_out; };
+enum { STEP_BULK = 0, STEP_COLLAPSE = 1, STEP_TAIL = 2 };
+
+static ReduceStep next_step(uint64_t n, uint32_t left)
+{
+    ReduceStep st;
+    if (n <= 128) {
+        st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
+    } else if (ceil_shift(n, 7) >= 2048) {
+        st.kind = STEP_BULK; st.levels = pick_m(n) + 1u; st.n_out = ceil_shift(n, st.levels);
+    } else {
+        st.kind = STEP_COLLAPSE; st.levels = 7; st.n_out = ceil_shift(n, 7);
+    }
+    return st;
+}
+
 size_t vkmr_hip_reduce_scratch_bytes(uint64_t count)
 {
-    // ping-pong: outputs of pass 1 and pass 2 (later passes are smaller)
+    // ping-pong: outputs of step 1 and step 2 (later steps are smaller)
     uint64_t n = count, total = 0;
-    for (int pass = 0; pass < 2 && n > VKMR_TAIL_MAX; ++pass) {
-        n = ceil_shift(n, pick_m(n) + 1);
+    for (int pass = 0; pass < 2 && n > 128; ++pass) {
+        n = next_step(n, 64).n_out;
         total += n;
     }
     return (size_t)(total + 2) * sizeof(vkmr_digest);
+}
+
+// Reduces `nslices` slices (n_full nodes each, the last n_last) through `height`
+// levels each; slice k's root goes to roots[k].  The step sequence is that of a full
+// slice; a shorter last slice rides along (its surplus wavefronts exit at once).
+static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32_t nslices, uint64_t n_full, uint64_t n_last,
+                                 uint32_t height, Node* scratch, Node* roots)
+{
+    const Node* in = digests;
+    uint64_t n = n_full, nl = n_last, in_stride = n_full;
+    uint32_t left = height;
+    Node* bufA = scratch;
+    Node* bufB = nullptr;
+    for (int pass = 0;; ++pass) {
+        const ReduceStep st = next_step(n, left);
+        SliceGeom g;
+        g.n_full = n; g.n_last = nl; g.in_stride = in_stride; g.nslices = nslices;
+        if (st.kind == STEP_TAIL) {
+            g.out_stride = 1;
+            hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(64), 0, stream, in, g, left, roots);
+            VKMR_TRY(hipGetLastError());
+            return VKMR_OK;
+        }
+        Node* out;
+        if (pass == 0) {
+            out = bufA;
+            bufB = bufA + st.n_out * nslices;
+        } else {
+            out = (pass & 1) ? bufB : bufA;
+        }
+        g.out_stride = st.n_out;
+        if (st.kind == STEP_BULK) {
+            const uint32_t m = st.levels - 1u;
+            const uint64_t waves = ceil_shift(n, 7 + m);
+            const uint64_t grid = (waves + VKMR_PASS_WAVES - 1) / VKMR_PASS_WAVES;
+            if (grid > 0x7fffffffull) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: slice too large");
+            hipLaunchKernelGGL(reduce_pass_kernel, dim3((uint32_t)grid, nslices), dim3(VKMR_PASS_WAVES * 64), 0, stream, in, g, out, m);
+        } else {
+            hipLaunchKernelGGL(reduce_collapse_kernel, dim3((uint32_t)ceil_shift(n, 7), nslices), dim3(64), 0, stream, in, g,
+                               st.levels, out);
+        }
+        VKMR_TRY(hipGetLastError());
+        in = out;
+        in_stride = st.n_out;
+        n = st.n_out;
+        nl = ceil_shift(nl, st.levels);
+        left -= st.levels;
+    }
 }
 
 vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint64_t count,
@@ -655,42 +772,30 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* dig
     if (!digests_dev || !root_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null pointer");
     if (!height_ok(count, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: height does not reduce count to one node");
-    if (count > VKMR_TAIL_MAX && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
+    if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
     VKMR_TRY(hipSetDevice(dev));
+    return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), 1, count, count, height,
+                         reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
+}
 
-    const Node* in = reinterpret_cast<const Node*>(digests_dev);
-    uint64_t n = count;
-    uint32_t left = height;
-    // scratch layout: [A: output of pass 1][B: output of pass 2]; later passes alternate
-    Node* bufA = reinterpret_cast<Node*>(scratch_dev);
-    Node* bufB = nullptr;
-    int pass = 0;
-    while (n > VKMR_TAIL_MAX) {
-        const uint32_t m = pick_m(n);
-        const uint64_t n_out = ceil_shift(n, m + 1);
-        Node* out;
-        if (pass == 0) {
-            out = bufA;
-            bufB = bufA + n_out;
-        } else {
-            out = (pass & 1) ? bufB : bufA;
-        }
-        const uint64_t waves = ceil_shift(n, 7 + m);
-        const uint64_t grid = (waves + VKMR_PASS_WAVES - 1) / VKMR_PASS_WAVES;
-        if (grid > 0x7fffffffull) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: slice too large");
-        hipLaunchKernelGGL(reduce_pass_kernel, dim3((uint32_t)grid), dim3(VKMR_PASS_WAVES * 64), 0, S(s), in, n, out, m);
-        VKMR_TRY(hipGetLastError());
-        in = out;
-        n = n_out;
-        left -= (m + 1);
-        ++pass;
-    }
-    uint32_t threads = (uint32_t)(((n + 1) / 2 + 63) / 64 * 64);
-    if (threads < 64) threads = 64;
-    hipLaunchKernelGGL(reduce_tail_kernel, dim3(1), dim3(threads), 0, S(s), in, (uint32_t)n, left,
-                       reinterpret_cast<Node*>(root_dev));
-    VKMR_TRY(hipGetLastError());
-    return VKMR_OK;
+size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
+{
+    return vkmr_hip_reduce_scratch_bytes(capacity) * (size_t)(nslices ? nslices : 1);
+}
+
+vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint32_t nslices,
+                                         uint64_t capacity, uint64_t count_last, uint32_t height, void* scratch_dev,
+                                         vkmr_digest* roots_dev)
+{
+    if (!digests_dev || !roots_dev || nslices == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad argument");
+    if (count_last == 0 || count_last > capacity || nslices > 65535u)
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad slice geometry");
+    if (!height_ok(capacity, height) || (nslices == 1 && !height_ok(count_last, height)))
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: height does not reduce a slice to one node");
+    if (capacity > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
+    VKMR_TRY(hipSetDevice(dev));
+    return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), nslices, nslices == 1 ? count_last : capacity,
+                         count_last, height, reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(roots_dev));
 }
 
 size_t vkmr_hip_reduce_levels_scratch_bytes(uint64_t count)

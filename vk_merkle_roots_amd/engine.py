@@ -174,6 +174,11 @@ class HipDevice:
                  root_buf.at(32 * root_index)),
               "vkmr_hip_reduce_async")
 
+    def reduce_slices_async(self, digests_buf, nslices, capacity, count_last, height, scratch_buf, roots_buf, stream=None):
+        check(self.lib.vkmr_hip_reduce_slices_async(self.index, stream or self.stream, digests_buf.ptr, nslices, capacity, count_last,
+                                                    height, scratch_buf.ptr if scratch_buf else None, roots_buf.ptr),
+              "vkmr_hip_reduce_slices_async")
+
     def reduce_scratch(self, count, levels_variant=False):
         fn = self.lib.vkmr_hip_reduce_levels_scratch_bytes if levels_variant else self.lib.vkmr_hip_reduce_scratch_bytes
         return self.alloc(fn(count))
@@ -217,6 +222,39 @@ class HipDevice:
 def digest_hex(words):
     """Canonical hex of a word-valued digest (big-endian bytes of H[0..7])."""
     return np.ascontiguousarray(words, dtype=np.uint32).astype(">u4").tobytes().hex()
+
+
+def merkle_root_packed_batched(dev, batch, slice_capacity, batch_strings=None):
+    """Same tree as merkle_root_packed, all slices resident and reduced by ONE
+    vkmr_hip_reduce_slices_async, slice roots combined on the device."""
+    n = batch.count
+    if n == 0:
+        return ""
+    nslices = (n + slice_capacity - 1) // slice_capacity
+    batch_strings = batch_strings or n
+    d_slices = dev.alloc(32 * nslices * slice_capacity)
+    for b0 in range(0, n, batch_strings):
+        b1 = min(n, b0 + batch_strings)
+        sub = batch.slice(b0, b1)
+        d_data = dev.upload(sub.data if sub.words else np.zeros(1, np.uint32))
+        d_meta = dev.upload(sub.meta)
+        dev.map_async(d_data, sub.words, d_meta, sub.count, d_slices, out_offset_digests=b0)
+        dev.sync()
+        d_data.free()
+        d_meta.free()
+    count_last = n - (nslices - 1) * slice_capacity
+    height = int(math.log2(slice_capacity)) if nslices > 1 else tree_height(n)
+    d_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_slices_scratch_bytes(slice_capacity, nslices))
+    d_roots = dev.alloc(32 * nslices)
+    dev.reduce_slices_async(d_slices, nslices, slice_capacity, count_last, height, d_scratch, d_roots)
+    if nslices > 1:
+        d_top = dev.reduce_scratch(nslices)
+        d_final = dev.alloc(32)
+        dev.reduce_async(d_roots, nslices, tree_height(nslices), d_top, d_final)
+        root = dev.download(d_final, 32)
+    else:
+        root = dev.download(d_roots, 32)
+    return digest_hex(root)
 
 
 def merkle_root_packed(dev, batch, slice_capacity=None, batch_strings=None, levels_variant=False):
