@@ -1,0 +1,128 @@
+"""The C++ front end (`vkmr`): same command line and output line as the reference's
+program, "CPU" backend everywhere, "hip:<n>" on the GPU box."""
+import hashlib
+import os
+import re
+import subprocess
+
+import pytest
+
+LINE = re.compile(r"^(?P<name>\S+): computed root \(of (?P<items>\d+) item\(s\), (?P<bytes>\d+) byte\(s\)\) => (?P<root>[0-9a-f]{64}) in [0-9.e+-]+$")
+
+
+def tool(native, name):
+    return os.path.join(os.path.dirname(native.HIP_LIB), "bin", name)
+
+
+def run_vkmr(native, backend, stream, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([tool(native, "vkmr")] + ([backend] if backend else []), input=stream, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=e, timeout=600)
+    out = r.stdout.decode().splitlines()
+    res = [LINE.match(l) for l in out]
+    res = [m for m in res if m]
+    return r, out, (res[-1].groupdict() if res else None)
+
+
+def golden_stream(native, s):
+    if "stream_hex" in s:
+        return bytes.fromhex(s["stream_hex"])
+    if s.get("generator", "").startswith("rndm"):
+        return subprocess.run([tool(native, "rndm")] + s["generator"].split()[1:], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    alpha = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
+    return subprocess.run([tool(native, "strm")] + ["%02d%s" % (i, alpha) for i in range(16)], stdout=subprocess.PIPE).stdout
+
+
+def test_cpu_backend_golden_streams(native, golden):
+    """BASELINE configs[0] (16 fixed 64 B strings via strm | vkmr CPU) and every other golden stream."""
+    for name, s in golden["streams"].items():
+        if name.startswith("G3"):
+            continue
+        r, out, m = run_vkmr(native, "CPU", golden_stream(native, s))
+        assert r.returncode == 0 and out[0] == "Initializing for: CPU", name
+        assert m and (m["name"], int(m["items"]), int(m["bytes"]), m["root"]) == ("CPU", s["items"], s["bytes"], s["root"]), name
+
+
+def test_cpu_backend_config2(native, golden):
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    data = golden_stream(native, s)
+    assert hashlib.sha256(data).hexdigest() == s["stream_sha256"]
+    r, out, m = run_vkmr(native, "CPU", data)
+    assert m and (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])
+
+
+def test_empty_input_prints_no_root(native):
+    r, out, m = run_vkmr(native, "CPU", b"")
+    assert r.returncode == 0 and m is None and out == ["Initializing for: CPU"]
+    assert b"Read an empty string?" in r.stderr
+    r, out, m = run_vkmr(native, "CPU", b"\n\n")
+    assert m is None and r.stderr.count(b"Read an empty string?") == 3
+
+
+def test_unknown_backend_aborts(native):
+    r, out, m = run_vkmr(native, "no-such-device", b"a\n")
+    assert r.returncode == 1 and b"No device selected; aborting." in r.stderr
+
+
+def test_default_backend_selection(native):
+    """No argument: the only backend is picked; with several the program lists them and exits 1
+    (reference Vkmr.cpp:72-84)."""
+    r, out, m = run_vkmr(native, None, b"a\nb\n")
+    if r.returncode == 0:
+        assert out[0] == "Initializing for: CPU" and m["root"]
+    else:
+        assert r.returncode == 1 and b"Available:" in r.stderr and b"* CPU" in r.stderr and b"* hip:0" in r.stderr
+
+
+def test_input_reader_block_boundaries(native, oracle):
+    """Lines straddling the reader's 1 MiB blocks, a very long line, CR kept."""
+    lines = [b"x" * 700000, b"y" * 700000, b"z" * 3000000, b"tail\r"]
+    data = b"\n".join(lines) + b"\n"
+    r, out, m = run_vkmr(native, "CPU", data)
+    want, cnt, nb = oracle.root_of_stream(data)
+    assert m and (m["root"], int(m["items"]), int(m["bytes"])) == (want, cnt, nb)
+
+
+@pytest.mark.gpu
+def test_hip_backend_golden_streams(native, golden):
+    for name, s in golden["streams"].items():
+        r, out, m = run_vkmr(native, "hip:0", golden_stream(native, s))
+        assert r.returncode == 0 and out[0] == "Initializing for: hip:0", (name, r.stderr[-500:])
+        assert m and (m["name"], int(m["items"]), int(m["bytes"]), m["root"]) == ("hip:0", s["items"], s["bytes"], s["root"]), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"VKMR_SLICE_LOG2": "10", "VKMR_BATCH_BYTES": "65536", "VKMR_MAX_INFLIGHT": "2"},
+    {"VKMR_SLICE_LOG2": "12", "VKMR_BATCH_BYTES": "20000", "VKMR_MAX_INFLIGHT": "1"},
+    {"VKMR_SLICE_LOG2": "16", "VKMR_BATCH_MB": "1", "VKMR_VERBOSE": "1"},
+    {"VKMR_SLICE_LOG2": "20", "VKMR_BATCH_MB": "4"},
+])
+def test_hip_backend_small_slices_and_batches(native, golden, env):
+    """Many batches per slice, many slices, back-pressure: always the golden root."""
+    for name in ("G2_rndm_1712489279_1024_127", "G6_rndm_7_1000_300", "G3_rndm_42_1048576_127", "L3_no_trailing_newline"):
+        s = golden["streams"][name]
+        r, out, m = run_vkmr(native, "hip:0", golden_stream(native, s), env)
+        assert r.returncode == 0, (name, r.stderr[-500:])
+        assert m and (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"]), (name, env)
+
+
+@pytest.mark.gpu
+def test_hip_backend_long_strings(native, golden):
+    s = golden["streams"]["G4_rndm_42_4096_4096"]
+    r, out, m = run_vkmr(native, "hip:0", golden_stream(native, s), {"VKMR_SLICE_LOG2": "11", "VKMR_BATCH_BYTES": "1000000"})
+    assert m and m["root"] == s["root"]
+
+
+@pytest.mark.gpu
+def test_hip_backend_empty_input(native):
+    r, out, m = run_vkmr(native, "hip:0", b"\n")
+    assert r.returncode == 0 and m is None
+
+
+@pytest.mark.gpu
+def test_hip_string_larger_than_batch_is_refused(native):
+    r, out, m = run_vkmr(native, "hip:0", b"a\n" + b"b" * 10000 + b"\nc\n", {"VKMR_BATCH_BYTES": "4096"})
+    assert b"does not fit an empty batch" in r.stderr
+    assert m and int(m["items"]) == 1   # the loop stops at the refused string, like the reference (Vkmr.cpp:44-47)

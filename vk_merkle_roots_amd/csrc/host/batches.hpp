@@ -1,0 +1,95 @@
+// batches.hpp -- packed input batches.
+//
+// A Batch is what the reference's vkmr::Batch is (src/vkmr/Batches.h:31-129): strings
+// packed back to back on 4-byte boundaries in a data buffer, plus one {start word,
+// size bytes} metadata entry per string, in memory the GPU side can consume.  On
+// MI355X the host side is pinned memory (allocated through the C ABI) and each batch
+// owns an HBM landing zone of the same size: Mappings copies host -> HBM on the
+// op's stream and the map kernel reads HBM.  Buffers are recycled through Batches
+// instead of being returned to the system after every mapping (the reference frees
+// them, src/vkmr/Mappings.cpp:328-329; recycling is its first to-do, README.md:113).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "vkmr_hip.h"
+
+namespace vkmr {
+
+class Batches;
+
+class Batch {
+    friend class Batches;
+
+public:
+    typedef uint32_t number_type;
+    typedef size_t size_type;
+
+    Batch() = default;
+    Batch(Batch&&) noexcept;
+    Batch& operator=(Batch&&) noexcept;
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
+    ~Batch() { Release(); }
+
+    explicit operator bool() const { return m_data != nullptr && m_meta != nullptr; }
+
+    size_type Count() const { return m_count; }          // strings in the batch
+    size_type Size() const { return m_bytes; }           // payload bytes
+    size_type Words() const { return m_words; }          // packed words used
+    bool Empty() const { return !(*this) || m_count == 0; }
+    number_type Number() const { return m_number; }
+    int Device() const { return m_dev; }
+
+    // Appends one string / a group of strings; false when it does not fit (the batch
+    // is unchanged).  Reference Batch::Push, src/vkmr/Batches.cpp:64-121.
+    bool Push(const char* p, size_t n);
+    bool Push(const std::vector<std::string>& strings);
+    // Drops the last `count` strings (reference Batch::Pop, src/vkmr/Batches.cpp:123-125).
+    void Pop(size_t count);
+
+    // host (pinned) and device views, for Mappings
+    const uint32_t* HostData() const { return m_data; }
+    const vkmr_metadata* HostMeta() const { return m_meta; }
+    uint32_t* DeviceData() const { return m_ddata; }
+    vkmr_metadata* DeviceMeta() const { return m_dmeta; }
+
+private:
+    void Release();
+
+    Batches* m_owner = nullptr;
+    int m_dev = -1;
+    uint32_t* m_data = nullptr;        // pinned host, data_words capacity
+    vkmr_metadata* m_meta = nullptr;   // pinned host, meta capacity
+    uint32_t* m_ddata = nullptr;       // HBM
+    vkmr_metadata* m_dmeta = nullptr;  // HBM
+    size_t m_cap_words = 0, m_cap_count = 0;
+    size_t m_count = 0, m_words = 0, m_bytes = 0;
+    number_type m_number = 0xFFFFFFFFu;
+};
+
+// Allocates and recycles batches for one device.
+class Batches {
+public:
+    // data_bytes: capacity of a batch's data buffer; metadata capacity follows the
+    // reference's ratio (one entry per 32 data bytes, src/vkmr/Batches.h:131-134).
+    Batches(int dev, size_t data_bytes);
+    ~Batches();
+    Batches(const Batches&) = delete;
+    Batches& operator=(const Batches&) = delete;
+
+    Batch New();                 // a fresh or recycled batch; falsy when allocation fails
+    void Recycle(Batch& b);      // called by Batch::Release
+    size_t InCirculation() const { return m_live; }
+
+private:
+    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; };
+    int m_dev;
+    size_t m_words, m_count, m_live;
+    uint32_t m_next;
+    std::vector<Buffers> m_free;
+};
+
+}  // namespace vkmr

@@ -1,0 +1,191 @@
+// hip_sha256d.cpp -- see hip_sha256d.hpp.  Control flow follows the reference's stream
+// processor (src/vkmr/SHA-256vk.cpp:288-429) with two simplifications HIP allows: a
+// sub-slice is a pointer offset, so strings go straight into the batch (no buffered
+// vector and no aligned reservation size, SHA-256vk.cpp:338-342), and a full pipeline
+// blocks on its oldest mapping instead of failing.
+#include "hip_sha256d.hpp"
+
+#include <cstdlib>
+#include <iostream>
+
+#include "util.hpp"
+
+namespace vkmr {
+
+HipConfig HipConfig::FromEnv()
+{
+    HipConfig c;
+    if (const char* e = getenv("VKMR_SLICE_LOG2")) c.slice_log2 = (uint32_t)atoi(e);
+    if (const char* e = getenv("VKMR_BATCH_MB")) c.batch_bytes = (size_t)atol(e) << 20;
+    if (const char* e = getenv("VKMR_BATCH_BYTES")) c.batch_bytes = (size_t)atol(e);
+    if (const char* e = getenv("VKMR_MAX_INFLIGHT")) c.max_inflight = (size_t)atol(e);
+    if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
+    if (c.slice_log2 < 1) c.slice_log2 = 1;
+    if (c.slice_log2 > 31) c.slice_log2 = 31;
+    if (c.batch_bytes < 4096) c.batch_bytes = 4096;
+    if (c.max_inflight < 1) c.max_inflight = 1;
+    return c;
+}
+
+HipSha256D::HipSha256D() : m_count(0)
+{
+    int n = 0;
+    if (vkmr_hip_device_count(&n) == VKMR_OK) m_count = n;
+}
+
+std::vector<ISha256D::name_type> HipSha256D::Available() const
+{
+    std::vector<ISha256D::name_type> names;
+    for (int i = 0; i < m_count; ++i) names.push_back("hip:" + std::to_string(i));
+    if (m_count > 1) names.push_back("hip:all");
+    return names;
+}
+
+bool HipSha256D::Has(const ISha256D::name_type& name) const
+{
+    for (const auto& n : Available())
+        if (n == name) return true;
+    return false;
+}
+
+std::unique_ptr<HipSha256D::Instance> HipSha256D::Get(const ISha256D::name_type& name, const HipConfig& cfg)
+{
+    std::vector<int> devs;
+    if (name == "hip:all") {
+        for (int i = 0; i < m_count; ++i) devs.push_back(i);
+    } else {
+        devs.push_back(atoi(name.c_str() + 4));
+    }
+    return std::unique_ptr<Instance>(new Instance(name, devs, cfg));
+}
+
+HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices, const HipConfig& cfg)
+    : ISha256D(name), m_cfg(cfg), m_slices(devices, (size_t)1 << cfg.slice_log2), m_ok(true)
+{
+    for (int d : devices) {
+        PerDevice pd;
+        pd.dev = d;
+        m_ok = m_ok && vkmr_hip_stream_create(d, &pd.map_stream) == VKMR_OK &&
+               vkmr_hip_stream_create(d, &pd.reduce_stream) == VKMR_OK;
+        pd.batches.reset(new Batches(d, cfg.batch_bytes));
+        if (cfg.verbose) {
+            char devname[256] = "";
+            size_t free_b = 0, total_b = 0;
+            int cus = 0, wave = 0;
+            vkmr_hip_device_name(d, devname, sizeof devname);
+            vkmr_hip_device_mem_info(d, &free_b, &total_b);
+            vkmr_hip_device_geometry(d, &cus, &wave);
+            std::cout << "hip:" << d << " \"" << devname << "\": " << cus << " CUs, wavefront " << wave << ", "
+                      << (free_b >> 20) << " of " << (total_b >> 20) << " MiB free" << std::endl;
+        }
+        m_devs.push_back(std::move(pd));
+    }
+    m_mappings = Mappings::New(cfg.verbose);
+    m_reductions = Reductions::New(devices.empty() ? 0 : devices.front(), cfg.verbose);
+    if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
+}
+
+HipSha256D::Instance::~Instance()
+{
+    // ops first (they hold batches and slices), then the pools and streams
+    m_mappings.reset();
+    m_reductions.reset();
+    m_batch = Batch();
+    m_slices = Slices();
+    for (auto& pd : m_devs) {
+        pd.batches.reset();
+        vkmr_hip_stream_destroy(pd.dev, pd.map_stream);
+        vkmr_hip_stream_destroy(pd.dev, pd.reduce_stream);
+    }
+}
+
+HipSha256D::Instance::PerDevice& HipSha256D::Instance::Dev(int dev)
+{
+    for (auto& pd : m_devs)
+        if (pd.dev == dev) return pd;
+    return m_devs.front();
+}
+
+// A retired mapping adds its strings to its slice's fill count; a filled slice goes
+// to reduction at once (reference SHA-256vk.cpp:321-335).
+void HipSha256D::Instance::Account(std::vector<Slice>&& retired)
+{
+    for (auto& sub : retired) {
+        Slice& slice = m_slices[sub.Number()];
+        if (!slice) continue;
+        slice += sub;
+        if (slice.IsFilled()) {
+            if (m_cfg.verbose) std::cout << "Slice #" << slice.Number() << " has been filled." << std::endl;
+            const int dev = slice.Device();
+            m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, Dev(dev).reduce_stream);
+        }
+    }
+}
+
+bool HipSha256D::Instance::MapCurrent()
+{
+    Slice& slice = m_slices.Current();
+    if (m_batch.Empty() || !slice) return true;
+    if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
+    PerDevice& pd = Dev(slice.Device());
+    return m_mappings->Map(std::move(m_batch), slice.Sub(), pd.map_stream) == VKMR_OK;
+}
+
+bool HipSha256D::Instance::StartSliceAndBatch()
+{
+    Slice& slice = m_slices.New();
+    if (!slice) return false;
+    m_batch = Dev(slice.Device()).batches->New();
+    return static_cast<bool>(m_batch);
+}
+
+bool HipSha256D::Instance::Add(const char* bytes, size_t size)
+{
+    if (!m_ok) return false;
+    // progress of in-flight work is discovered here, on the caller's thread
+    // (reference SHA-256vk.cpp:318-335)
+    m_reductions->Update();
+    if (m_mappings->InFlight()) Account(m_mappings->Update());
+
+    if (!m_slices.Current()) {
+        if (!StartSliceAndBatch()) return (m_ok = false);
+    } else if (m_slices.Current().Available() == 0) {
+        // the slice is fully reserved: send off what is batched and open the next slice
+        if (!MapCurrent() || !StartSliceAndBatch()) return (m_ok = false);
+    }
+    if (!m_batch.Push(bytes, size)) {
+        // batch full: map it and continue in a fresh one on the same device
+        const int dev = m_slices.Current().Device();
+        if (!MapCurrent()) return (m_ok = false);
+        m_batch = Dev(dev).batches->New();
+        if (!m_batch || !m_batch.Push(bytes, size)) {
+            std::cerr << "A string of " << size << " byte(s) does not fit an empty batch." << std::endl;
+            return (m_ok = false);
+        }
+    }
+    return m_slices.Current().Reserve(1);
+}
+
+ISha256D::out_type HipSha256D::Instance::Root()
+{
+    if (!m_ok) return "";
+    // residual batch, then every mapping (reference SHA-256vk.cpp:291-299)
+    const bool single = m_slices.LastNumber() <= 1;
+    if (!MapCurrent()) return "";
+    Account(m_mappings->WaitFor());
+    // every remaining slice (at most the last, partial one): slice #1 alone is
+    // reduced over its own count, any other to full capacity height
+    // (reference Reductions.cpp:471; SHA-256vk.cpp:301-311)
+    while (m_slices.Has()) {
+        const Slice& any = m_slices.Any();
+        const uint32_t number = any.Number();
+        Slice s = m_slices.Remove(number);
+        if (!s || s.Count() == 0) continue;
+        const uint32_t height = (single && number == 1) ? tree_height(s.Count()) : m_cfg.slice_log2;
+        const int dev = s.Device();
+        m_reductions->Reduce(std::move(s), height, Dev(dev).reduce_stream);
+    }
+    return m_reductions->WaitFor();
+}
+
+}  // namespace vkmr

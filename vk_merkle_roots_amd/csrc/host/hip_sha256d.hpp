@@ -1,0 +1,74 @@
+// hip_sha256d.hpp -- the GPU backend: HIP devices by name, and the stream processor.
+//
+// Takes the place of the reference's vkmr::VkSha256D / VkSha256D::Instance
+// (src/vkmr/SHA-256vk.h:31-85): `HipSha256D` enumerates devices and hands out one
+// `Instance` per name ("hip:0", "hip:1", ..., and "hip:all" to shard slices across
+// every GPU of the node); an Instance is an ISha256D whose Add() streams strings
+// into batches -> mappings -> slices -> reductions, all asynchronous, and whose
+// Root() drains the pipeline and combines the slice roots.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "isha256d.hpp"
+#include "ops.hpp"
+
+namespace vkmr {
+
+struct HipConfig {
+    uint32_t slice_log2 = 23;        // digests per slice: 2^23 = 256 MiB, the reference's slice (SHA-256vk.cpp:23)
+    size_t batch_bytes = 256u << 20; // data bytes per batch: the reference's MegaX (SHA-256vk.cpp:23, :247-248)
+    size_t max_inflight = 4;         // mappings in flight before Add() blocks on the oldest
+    bool verbose = false;            // per-op log lines like the reference prints
+    static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_MAX_INFLIGHT, VKMR_VERBOSE
+};
+
+class HipSha256D {
+public:
+    class Instance;
+
+    HipSha256D();
+    explicit operator bool() const { return m_count > 0; }
+    bool Has(const ISha256D::name_type&) const;
+    // One use per name, like the reference's Get (SHA-256vk.cpp:224-229).
+    std::unique_ptr<Instance> Get(const ISha256D::name_type&, const HipConfig& cfg = HipConfig::FromEnv());
+    std::vector<ISha256D::name_type> Available() const;
+
+private:
+    int m_count;
+};
+
+class HipSha256D::Instance : public ISha256D {
+public:
+    Instance(const std::string& name, std::vector<int> devices, const HipConfig& cfg);
+    ~Instance() override;
+
+    out_type Root() override;
+    bool Add(const arg_type& arg) override { return Add(arg.data(), arg.size()); }
+    bool Add(const char* bytes, size_t size) override;
+    bool Reset() override { return false; }   // reference IVkSha256DInstance::Reset, SHA-256vk.h:28
+
+    bool Ok() const { return m_ok; }
+
+private:
+    struct PerDevice {
+        int dev;
+        vkmr_stream map_stream = nullptr, reduce_stream = nullptr;
+        std::unique_ptr<Batches> batches;
+    };
+    PerDevice& Dev(int dev);
+    bool MapCurrent();                                   // dispatches m_batch into the current slice's pending reservations
+    void Account(std::vector<Slice>&& retired);          // retired sub-slices -> fill counts -> reductions
+    bool StartSliceAndBatch();
+
+    HipConfig m_cfg;
+    std::vector<PerDevice> m_devs;
+    Slices m_slices;
+    Batch m_batch;
+    std::unique_ptr<Mappings> m_mappings;
+    std::unique_ptr<Reductions> m_reductions;
+    bool m_ok;
+};
+
+}  // namespace vkmr

@@ -1,0 +1,47 @@
+// inputs.hpp -- line reader for the input stream.
+//
+// Same contract as the reference's vkmr::Input (src/vkmr/Inputs.h:20-47,
+// src/vkmr/Inputs.cpp:52-101): '\n' or end of file ends a line, '\r' is kept, Has() is
+// "not at end of file yet" -- so a stream that ends in '\n' yields one final empty
+// string, which the caller skips with a warning (src/vkmr/Vkmr.cpp:40-43).  The
+// reference reads with one fgetc + append per byte; this reader pulls 1 MiB blocks
+// with fread and splits with memchr.
+#pragma once
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace vkmr {
+
+class Input {
+public:
+    typedef size_t size_type;
+
+    explicit Input(FILE* fp, bool owner = false);
+    explicit Input(const std::string& path);
+    Input(const Input&) = delete;
+    Input& operator=(const Input&) = delete;
+    ~Input();
+
+    explicit operator bool() const { return m_fp != nullptr; }
+
+    bool Has() const { return !m_eof; }
+    std::string Get();
+    // Zero-copy form of Get(): pointer/length stay valid until the next call.
+    bool GetView(const char** p, size_t* n);
+
+    size_type Size() const { return m_size; }
+    size_type Count() const { return m_count; }
+
+private:
+    bool Fill();
+
+    FILE* m_fp;
+    bool m_owner, m_eof;
+    size_type m_size, m_count;
+    std::vector<char> m_buf;
+    size_t m_pos, m_end;
+    std::string m_carry;
+};
+
+}  // namespace vkmr

@@ -1,0 +1,109 @@
+// mappings.cpp -- in-flight mappings (reference src/vkmr/Mappings.cpp:294-365, without
+// the descriptor/command-buffer machinery: one mapping = two async copies + one kernel
+// launch + events on the op's stream).
+#include <iostream>
+
+#include "ops.hpp"
+
+namespace vkmr {
+namespace {
+
+struct Mapping {
+    Batch batch;
+    Slice sub;
+    vkmr_event begin = nullptr, done = nullptr;
+    int dev = -1;
+};
+
+class MappingsImpl : public Mappings {
+public:
+    explicit MappingsImpl(bool verbose) : m_verbose(verbose) {}
+    ~MappingsImpl() override
+    {
+        WaitFor();
+        for (auto& e : m_spare) vkmr_hip_event_destroy(e.first, e.second);
+    }
+
+    HipResult Map(Batch&& batch, slice_type&& sub, vkmr_stream stream) override
+    {
+        if (batch.Empty() || !sub) return VKMR_OK;   // nothing to do
+        Mapping m;
+        m.dev = sub.Device();
+        m.begin = Event(m.dev);
+        m.done = Event(m.dev);
+        if (!m.begin || !m.done) return VKMR_ERR_HIP;
+        HipResult r = vkmr_hip_event_record(m.dev, m.begin, stream);
+        if (r == VKMR_OK)
+            r = vkmr_hip_memcpy_h2d_async(m.dev, stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
+        if (r == VKMR_OK)
+            r = vkmr_hip_memcpy_h2d_async(m.dev, stream, batch.DeviceMeta(), batch.HostMeta(),
+                                          batch.Count() * sizeof(vkmr_metadata));
+        if (r == VKMR_OK)
+            r = vkmr_hip_map_async(m.dev, stream, batch.DeviceData(), batch.Words(), batch.DeviceMeta(),
+                                   (uint32_t)batch.Count(), sub.Cells());
+        if (r == VKMR_OK) r = vkmr_hip_event_record(m.dev, m.done, stream);
+        if (r != VKMR_OK) {
+            std::cerr << "Failed to dispatch a mapping: " << vkmr_hip_last_error() << std::endl;
+            return r;
+        }
+        m.batch = std::move(batch);
+        m.sub = std::move(sub);
+        m_inflight.push_back(std::move(m));
+        return VKMR_OK;
+    }
+
+    std::vector<slice_type> Update() override { return Retire(false, (size_t)-1); }
+    std::vector<slice_type> WaitFor() override { return Retire(true, 0); }
+    std::vector<slice_type> WaitUntilAtMost(size_t limit) override { return Retire(true, limit); }
+    size_t InFlight() const override { return m_inflight.size(); }
+
+private:
+    vkmr_event Event(int dev)
+    {
+        for (size_t i = 0; i < m_spare.size(); ++i)
+            if (m_spare[i].first == dev) {
+                vkmr_event e = m_spare[i].second;
+                m_spare.erase(m_spare.begin() + i);
+                return e;
+            }
+        vkmr_event e = nullptr;
+        if (vkmr_hip_event_create(dev, &e) != VKMR_OK) return nullptr;
+        return e;
+    }
+
+    // Retires finished mappings, oldest first.  With `block`, waits for the oldest
+    // until no more than `keep` remain.
+    std::vector<slice_type> Retire(bool block, size_t keep)
+    {
+        std::vector<slice_type> out;
+        for (auto it = m_inflight.begin(); it != m_inflight.end();) {
+            HipResult st = vkmr_hip_event_query(it->dev, it->done);
+            if (st == VKMR_NOT_READY && block && m_inflight.size() > keep) st = vkmr_hip_event_wait(it->dev, it->done);
+            if (st == VKMR_NOT_READY) {
+                ++it;
+                continue;
+            }
+            if (m_verbose) {
+                float ms = 0.f;
+                vkmr_hip_event_elapsed_ms(it->dev, it->begin, it->done, &ms);
+                std::cout << "Mapping for slice #" << it->sub.Number() << " (" << it->sub.Reserved() << " item(s); "
+                          << it->batch.Size() << " byte(s)) finished in " << ms << "ms." << std::endl;
+            }
+            m_spare.emplace_back(it->dev, it->begin);
+            m_spare.emplace_back(it->dev, it->done);
+            out.push_back(std::move(it->sub));
+            it = m_inflight.erase(it);   // the batch goes back to its pool here
+        }
+        return out;
+    }
+
+    bool m_verbose;
+    std::vector<Mapping> m_inflight;
+    std::vector<std::pair<int, vkmr_event>> m_spare;
+};
+
+}  // namespace
+
+std::unique_ptr<Mappings> Mappings::New(bool verbose) { return std::unique_ptr<Mappings>(new MappingsImpl(verbose)); }
+
+}  // namespace vkmr

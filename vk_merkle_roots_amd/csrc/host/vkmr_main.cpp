@@ -1,0 +1,71 @@
+// vkmr_main.cpp -- `vkmr [backend]`: newline-separated strings on stdin, Merkle root of
+// their SHA-256d hashes on stdout.
+//
+// Same command line and output as the reference's main/run (src/vkmr/Vkmr.cpp:28-97):
+// backend "CPU" or a device name -- here "hip:<n>" / "hip:all" instead of a Vulkan
+// device name; with no argument and more than one backend it lists them and exits 1.
+#include <cstdio>
+#include <iostream>
+#include <string>
+
+#include "cpu_sha256d.hpp"
+#include "hip_sha256d.hpp"
+#include "inputs.hpp"
+#include "util.hpp"
+
+// The input loop (reference run(), src/vkmr/Vkmr.cpp:28-58).
+static int run(vkmr::ISha256D& backend)
+{
+    vkmr::Input input(stdin);
+    size_t size = 0, count = 0;
+    vkmr::StopWatch sw;
+    sw.Start();
+    while (input.Has()) {
+        const char* p = nullptr;
+        size_t n = 0;
+        input.GetView(&p, &n);
+        if (n == 0) {
+            std::cerr << "Read an empty string?" << std::endl;
+            continue;
+        }
+        if (!backend.Add(p, n)) break;
+        size += n;
+        ++count;
+    }
+    if (count > 0) {
+        const std::string root = backend.Root();
+        const double elapsed = sw.Elapsed();
+        std::cout << backend.Name() << ": computed root (of " << count << " item(s), " << size << " byte(s)) => " << root
+                  << " in " << elapsed << std::endl;
+    }
+    return 0;
+}
+
+int main(int argc, const char* argv[])
+{
+    vkmr::CpuSha256D cpu;
+    vkmr::HipSha256D gpus;
+    std::string choice;
+    if (argc > 1) {
+        choice = argv[1];
+    } else {
+        std::vector<std::string> available = gpus.Available();
+        available.insert(available.begin(), cpu.Name());
+        if (available.size() == 1) {
+            choice = available.front();
+        } else {
+            std::cerr << "Usage: " << argv[0] << " <name of compute device>" << std::endl;
+            std::cerr << "Available: " << std::endl;
+            for (const auto& name : available) std::cerr << "* " << name << std::endl;
+            return 1;
+        }
+    }
+    std::cout << "Initializing for: " << choice << std::endl;
+    if (gpus.Has(choice)) {
+        auto instance = gpus.Get(choice);
+        return run(*instance);
+    }
+    if (cpu.Name() == choice) return run(cpu);
+    std::cerr << "No device selected; aborting." << std::endl;
+    return 1;
+}
