@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-log2", type=int, default=22, help="prefix of the stream given to the CPU baseline")
     p.add_argument("--levels-variant", action="store_true", help="use the one-level-per-launch reduction")
+    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsal)")
+    p.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (plumbing check)")
     return p.parse_args()
 
 
@@ -94,12 +96,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    tdev = None
+    if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if a.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            tdev = torch.device("cuda", local_rank)
+            dist.init_process_group(backend="nccl", device_id=tdev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
+            local_rank = local_rank % max(1, torch.cuda.device_count())
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
@@ -132,16 +141,14 @@ def main():
     d_top_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_scratch_bytes(max(nslices * world, 2)) + 64)
     d_all_roots = dev.alloc(32 * nslices * world)
     d_final = dev.alloc(32)
-    slice_height = a.slice_log2 if (nslices * world > 1) else tree_height(n)
+    slice_height = min(a.slice_log2, a.leaves_log2) if (nslices * world > 1) else tree_height(n)
 
     ev = [(dev.new_event(), dev.new_event()) for _ in range(2 * a.steps * (nbatches + 1))]
     used = []
     host_roots = np.zeros((nslices, 8), dtype=np.uint32)
     final = np.zeros(8, dtype=np.uint32)
     if dist is not None:
-        import torch
-        t_mine = torch.zeros(nslices * 8, dtype=torch.int32, device="cuda")
-        t_all = [torch.zeros(nslices * 8, dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
+        from vk_merkle_roots_amd.distributed import gather_roots
 
     def step(timed):
         # MAP: one launch per batch into its place in the slice(s)
@@ -179,10 +186,9 @@ def main():
         else:
             vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, host_roots.ctypes.data, d_roots.ptr, 32 * nslices), "d2h")
             dev.sync()
-            t_mine.copy_(torch.from_numpy(host_roots.view(np.int32).reshape(-1)))
-            dist.gather(t_mine, t_all, dst=0)
+            allr = gather_roots(host_roots, dist, rank, world, device=tdev, equal_counts=True)   # ONE RCCL gather, 32 B per slice
             if rank == 0:
-                allr = torch.cat(t_all).cpu().numpy().view(np.uint32).reshape(-1, 8)
+                allr = np.ascontiguousarray(allr)
                 vk.check(dev.lib.vkmr_hip_memcpy_h2d_async(dev.index, dev.stream, d_all_roots.ptr, allr.ctypes.data, allr.nbytes), "h2d")
                 dev.reduce_async(d_all_roots, allr.shape[0], tree_height(allr.shape[0]), d_top_scratch, d_final)
                 vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, d_final.ptr, 32), "d2h")
@@ -193,7 +199,9 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev is not None:
+                torch.cuda.synchronize()
+        dev.sync()
 
     for _ in range(a.warmup):
         step(False)
@@ -205,7 +213,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

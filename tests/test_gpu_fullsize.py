@@ -1,0 +1,76 @@
+"""BASELINE.json's full sizes on the GPU: configs[2] (rndm 2^26 x 127 B) against the
+threaded oracle and through size-independent properties (any slicing gives the same
+root; both reduction variants agree), and configs[4] in miniature-at-scale (2^18 x 4 KiB
+strings: the multi-block padding path)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_digests(gpu, batch, batch_strings):
+    d_out = gpu.alloc(32 * batch.count)
+    for b0 in range(0, batch.count, batch_strings):
+        sub = batch.slice(b0, min(batch.count, b0 + batch_strings))
+        d_data, d_meta = gpu.upload(sub.data), gpu.upload(sub.meta)
+        gpu.map_async(d_data, sub.words, d_meta, sub.count, d_out, out_offset_digests=b0)
+        gpu.sync()
+        d_data.free()
+        d_meta.free()
+    return d_out
+
+
+def test_config3_2p26_leaves(gpu, oracle):
+    import vk_merkle_roots_amd as vk
+    from vk_merkle_roots_amd.engine import digest_hex, tree_height
+    n = 1 << 26
+    batch = vk.rndm_packed(42, n, 127)
+    assert batch.count == n
+    d_digests = gpu_digests(gpu, batch, 1 << 23)
+
+    # (1) the oracle, threaded, on the same packed input: every leaf digest and the root
+    want_leaves = oracle.leaves_packed(batch.data, batch.meta, threads=64)
+    got = gpu.download(d_digests, 32 * n).reshape(-1, 8)
+    assert (got == want_leaves).all()
+    del got
+    want_root = oracle.hex(oracle.root(want_leaves, threads=64))
+    del want_leaves
+
+    # (2) 8 slices of 2^23 reduced by one batched call + on-device combine
+    d_scratch = gpu.alloc(gpu.lib.vkmr_hip_reduce_slices_scratch_bytes(1 << 23, 8))
+    d_roots = gpu.alloc(32 * 8)
+    gpu.reduce_slices_async(d_digests, 8, 1 << 23, 1 << 23, 23, d_scratch, d_roots)
+    d_top, d_final = gpu.reduce_scratch(8), gpu.alloc(32)
+    gpu.reduce_async(d_roots, 8, 3, d_top, d_final)
+    root_8 = digest_hex(gpu.download(d_final, 32))
+    assert root_8 == want_root
+
+    # (3) slicing does not matter: one slice of 2^26, and 64 slices of 2^20, same root
+    d_s1 = gpu.reduce_scratch(n)
+    gpu.reduce_async(d_digests, n, 26, d_s1, d_final)
+    assert digest_hex(gpu.download(d_final, 32)) == want_root
+    d_s64 = gpu.alloc(gpu.lib.vkmr_hip_reduce_slices_scratch_bytes(1 << 20, 64))
+    d_r64 = gpu.alloc(32 * 64)
+    gpu.reduce_slices_async(d_digests, 64, 1 << 20, 1 << 20, 20, d_s64, d_r64)
+    gpu.reduce_async(d_r64, 64, 6, d_top, d_final)
+    assert digest_hex(gpu.download(d_final, 32)) == want_root
+
+    # (4) ragged: drop the last 12345 leaves -> last slice short, reduced to capacity height
+    m = n - 12345
+    gpu.reduce_slices_async(d_digests, 8, 1 << 23, m - 7 * (1 << 23), 23, d_scratch, d_roots)
+    gpu.reduce_async(d_roots, 8, 3, d_top, d_final)
+    ragged_sliced = digest_hex(gpu.download(d_final, 32))
+    gpu.reduce_async(d_digests, m, tree_height(m), d_s1, d_final)
+    assert digest_hex(gpu.download(d_final, 32)) == ragged_sliced
+
+
+def test_config5_long_strings(gpu, oracle):
+    """rndm <seed> 2^18 4096: lengths 1..4095, 1..65 blocks per string (BASELINE configs[4] at 1/64 of its count)."""
+    import vk_merkle_roots_amd as vk
+    n = 1 << 18
+    batch = vk.rndm_packed(11, n, 4096)
+    d_digests = gpu_digests(gpu, batch, 1 << 16)
+    got = gpu.download(d_digests, 32 * n).reshape(-1, 8)
+    want = oracle.leaves_packed(batch.data, batch.meta, threads=64)
+    assert (got == want).all()
+    assert vk.merkle_root_packed_batched(gpu, batch, slice_capacity=1 << 16, batch_strings=1 << 15) == oracle.hex(oracle.root(want, threads=64))

@@ -58,6 +58,9 @@ SIGNATURES = {
 }
 
 HOST_SIGNATURES = {
+    "vkmr_host_cpu_leaves": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "vkmr_host_cpu_reduce": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "vkmr_host_cpu_combine": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "vkmr_host_rndm_pack": (C.c_int64, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                         C.POINTER(C.c_uint64)]),
     "vkmr_host_rndm_rand": (None, [C.c_uint32, C.c_void_p, C.c_uint64]),

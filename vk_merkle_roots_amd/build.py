@@ -75,7 +75,7 @@ def build_host(force=False):
     def need(target, srcs):
         return force or not _newer(target, srcs + hdrs)
 
-    lib_srcs = [os.path.join(HOST, f) for f in ("stream_pack.cpp", "rndm_stream.cpp") if os.path.exists(os.path.join(HOST, f))]
+    lib_srcs = [os.path.join(HOST, f) for f in ("stream_pack.cpp", "rndm_stream.cpp", "host_api.cpp", "cpu_sha256d.cpp") if os.path.exists(os.path.join(HOST, f))]
     if lib_srcs and need(HOST_LIB, lib_srcs):
         _run([cxx] + flags + ["-shared", "-fPIC", "-fvisibility=hidden", "-o", HOST_LIB] + lib_srcs)
     built.append(HOST_LIB)

@@ -159,8 +159,10 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
         if (!MapCurrent()) return (m_ok = false);
         m_batch = Dev(dev).batches->New();
         if (!m_batch || !m_batch.Push(bytes, size)) {
+            // refuse this string only: what was added before still has a root
+            // (the caller stops reading and prints it, reference Vkmr.cpp:44-55)
             std::cerr << "A string of " << size << " byte(s) does not fit an empty batch." << std::endl;
-            return (m_ok = false);
+            return false;
         }
     }
     return m_slices.Current().Reserve(1);
