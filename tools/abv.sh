@@ -1,0 +1,12 @@
+#!/bin/bash
+# interleaved timing of VKMR_MAP_VARIANT values in one gpurun call.  Usage: bash tools/abv.sh "<bench args>" 0 5 6 ...
+ARGS=$1; shift
+for round in 1 2; do
+  for v in "$@"; do
+    VKMR_MAP_VARIANT=$v timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.readlines()[-1])
+w = d['valu_roofline']
+print('variant $v round', $round, 'ms/step', round(d['ms_per_step'], 3), 'map', round(w['map_ms_per_step'], 3), 'reduce', round(w['reduce_ms_per_step'], 3), d['root'][:12])"
+  done
+done

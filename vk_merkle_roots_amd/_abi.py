@@ -90,6 +90,10 @@ def lib():
     """The HIP extension.  Raises when it is not built -- never falls back."""
     global _lib
     if _lib is None:
+        path = os.environ.get("VKMR_HIP_LIB", HIP_LIB)      # alternative build of the SAME extension, for A/B timing
+        if path != HIP_LIB and os.path.exists(path):
+            _lib = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), SIGNATURES)
+            return _lib
         if not os.path.exists(HIP_LIB):
             raise RuntimeError(f"{HIP_LIB} is missing: run `python -m vk_merkle_roots_amd.build` "
                                "(the HIP extension is required; there is no CPU fallback)")

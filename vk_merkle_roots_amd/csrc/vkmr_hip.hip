@@ -23,32 +23,56 @@ using vkmr_dev::Node;
 // MAP
 // ============================================================================
 //
-// One workgroup (256 lanes = 4 wavefronts) maps one TILE of up to 512 consecutive
-// strings:
+// One workgroup maps one TILE of up to 2048 consecutive strings:
 //   1. metadata -> LDS, block count per string, counting sort of the tile by block
 //      count (longest first) so that the 64 lanes of a wavefront run the same number
 //      of compressions -- one lane per string without the sort runs every wavefront
 //      at the pace of its longest string;
-//   2. the tile's packed bytes, contiguous in the batch (Batch::Push layout), are
-//      copied into LDS with coalesced 16-byte HBM loads (H5); a tile whose bytes do
-//      not fit (long strings) or whose metadata is not contiguous reads HBM per lane;
-//   3. wavefronts pull groups of 64 sorted strings and hash them: 16-word message
-//      blocks from LDS, byte swap, 0x80 / zero / bit-length padding by masks (no
-//      branches), 64 unrolled rounds with the schedule ring in VGPRs.
+//   2. wavefronts pull groups of 64 sorted strings and hash them block by block:
+//      16 message words per lane, byte swap, 0x80 / zero / bit-length padding by masks
+//      (no branches), 64 unrolled rounds with the schedule ring in VGPRs.
+// How the 16 words reach the lane is the template parameter MODE (all three are kept,
+// parity-tested and timed against each other; profiles/r01_map_fetch_modes.txt):
+//   MODE 2 (shipped)  four 16-byte loads per lane straight from HBM/L2 -- the strings of a
+//                     tile are contiguous, so the tile's lines are shared through L2 and
+//                     each 128-byte line is fetched from HBM once; no LDS, 7 waves/SIMD;
+//   MODE 0            the tile's packed bytes copied to LDS with coalesced 16-byte loads,
+//                     lanes read LDS (the layout the north star describes);
+//   MODE 1            per-wavefront gather: 16 lanes read one string's 64 contiguous
+//                     bytes, four strings per load, transposed through LDS rows.
+// The kernel is bound by VALU issue, not by bytes, and MODE 2 frees the LDS and the
+// wave slots the other two hold during staging, so it is the fastest of the three.
 // Digest i lands in out[i] whatever the processing order.
 
 #define VKMR_MAP_STAGE_PAD 32
+#define VKMR_MAP_GATHER_STRIDE 20   // words per string row in the gather area: 80 B keeps ds_read_b128 conflict-free
 #define VKMR_MAP_BINS 64
+
+#ifdef VKMR_MAP_STAMPS
+// Diagnostic build only (tools/map_stamps.py): per-phase shader-clock totals of the map
+// kernel, accumulated by lane 0 of every workgroup.  Never compiled into the product.
+__device__ unsigned long long g_map_stamps[32768 * 8];   // 8 words per workgroup, no atomics
+#define VKMR_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define VKMR_STAMP(var)
+#endif
 
 __device__ __forceinline__ uint32_t block_count(uint32_t size) { return (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u; }
 
 // THREADS lanes per workgroup, tiles of at most MAX_TILE strings, STAGE_WORDS words of LDS staging.
-template <int THREADS, int MAX_TILE, int STAGE_WORDS>
+// GATHER selects how a tile that is not staged reads HBM: per wavefront through LDS rows
+// (the long-string kernel) or, in the short-string kernel where that is the rare
+// exception, simply per lane.
+// FULLFAST adds a wave-uniform fast path for blocks in which every string of the group
+// still has 64 bytes (long strings); short-string batches are faster without the test.
+template <int THREADS, int MAX_TILE, int STAGE_WORDS, int MODE, bool FULLFAST = false>
 __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
                                                       const vkmr_metadata* __restrict__ meta, uint32_t count,
                                                       Node* __restrict__ out, uint32_t tile)
 {
     constexpr int VKMR_MAP_THREADS = THREADS, VKMR_MAP_MAX_TILE = MAX_TILE, VKMR_MAP_STAGE_WORDS = STAGE_WORDS;
+    constexpr bool GATHER = (MODE == 1);   // MODE 0: stage tiles in LDS; 1: per-wavefront gather; 2: per-lane 16-byte loads
+    static_assert(!GATHER || STAGE_WORDS >= (THREADS / 64) * 64 * VKMR_MAP_GATHER_STRIDE, "staging area must hold the gather rows");
     __shared__ uint4 s_stage4[(VKMR_MAP_STAGE_WORDS + VKMR_MAP_STAGE_PAD) / 4];
     __shared__ uint2 s_meta[VKMR_MAP_MAX_TILE];
     __shared__ uint16_t s_order[VKMR_MAP_MAX_TILE];
@@ -63,6 +87,12 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
     if (tile_base >= count) return;
     const uint32_t n_tile = (uint32_t)((count - tile_base < tile) ? count - tile_base : tile);
 
+    VKMR_STAMP(t_begin);
+    // The prologue (sort + staging) is a few hundred instructions; a freshly launched
+    // workgroup is the youngest on its SIMDs and would otherwise be starved by the older
+    // workgroups' hashing, holding its LDS and wave slots idle.  Raise its issue priority
+    // until it starts hashing itself.
+    __builtin_amdgcn_s_setprio(3);
     if (tid < VKMR_MAP_BINS) s_hist[tid] = 0u;
     if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; s_next = 0u; }
     __syncthreads();
@@ -70,13 +100,21 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
     // ---- 1. metadata, keys, extent of the tile's packed bytes -------------------------
     constexpr int PER = VKMR_MAP_MAX_TILE / VKMR_MAP_THREADS;
     uint32_t key[PER], rank[PER];
+    uint2 mdv[PER];
     unsigned long long lo = ~0ull, hi = 0ull;
+    // all metadata loads of this lane are issued before any is used (one HBM round trip)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = tid + k * VKMR_MAP_THREADS;
+        mdv[k] = make_uint2(0u, 0u);
+        if (i < n_tile) mdv[k] = reinterpret_cast<const uint2*>(meta)[tile_base + i];
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const uint32_t i = tid + k * VKMR_MAP_THREADS;
         key[k] = 0u; rank[k] = 0u;
         if (i < n_tile) {
-            const uint2 md = reinterpret_cast<const uint2*>(meta)[tile_base + i];
+            const uint2 md = mdv[k];
             s_meta[i] = md;
             const uint32_t nb = block_count(md.y);
             key[k] = nb < VKMR_MAP_BINS ? nb : (VKMR_MAP_BINS - 1u);
@@ -108,28 +146,41 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
         if (i < n_tile) s_order[s_binstart[key[k]] + rank[k]] = (uint16_t)i;
     }
 
+    VKMR_STAMP(t_sorted);
     // ---- 3. stage the tile's packed words (coalesced) -------------------------------------
     const unsigned long long t_lo = s_lo, t_hi = s_hi;
     const unsigned long long a0 = t_lo & ~3ull;                 // 16-byte aligned start
-    const bool staged = (t_hi >= t_lo) && (t_hi - a0 <= VKMR_MAP_STAGE_WORDS) && (t_hi <= data_words) &&
+    const bool staged = (MODE == 0) && (t_hi >= t_lo) && (t_hi - a0 <= VKMR_MAP_STAGE_WORDS) && (t_hi <= data_words) &&
                         ((reinterpret_cast<uintptr_t>(data) & 15u) == 0u);
     const uint32_t span = staged ? (uint32_t)(t_hi - a0) : 0u;  // words staged
     if (staged) {
+        // every lane issues all of its 16-byte loads, then all of its LDS stores
         const uint4* src4 = reinterpret_cast<const uint4*>(data + a0);
-        for (uint32_t w = tid * 4u; w < span; w += VKMR_MAP_THREADS * 4u) {
-            uint4 v;
-            if (a0 + w + 4u <= data_words) {
-                v = src4[w >> 2];
-            } else {   // last, partial vector of the buffer
-                v.x = data[a0 + w];
-                v.y = (a0 + w + 1u < data_words) ? data[a0 + w + 1u] : 0u;
-                v.z = (a0 + w + 2u < data_words) ? data[a0 + w + 2u] : 0u;
-                v.w = 0u;
+        constexpr int NV = (VKMR_MAP_STAGE_WORDS / 4 + VKMR_MAP_THREADS - 1) / VKMR_MAP_THREADS;
+        uint4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const uint32_t w = (tid + q * VKMR_MAP_THREADS) * 4u;
+            v[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (w < span) {
+                if (a0 + w + 4u <= data_words) {
+                    v[q] = src4[w >> 2];
+                } else {   // last, partial vector of the buffer
+                    v[q].x = data[a0 + w];
+                    v[q].y = (a0 + w + 1u < data_words) ? data[a0 + w + 1u] : 0u;
+                    v[q].z = (a0 + w + 2u < data_words) ? data[a0 + w + 2u] : 0u;
+                }
             }
-            s_stage4[w >> 2] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const uint32_t w = (tid + q * VKMR_MAP_THREADS) * 4u;
+            if (w < span) s_stage4[w >> 2] = v[q];
         }
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    VKMR_STAMP(t_staged);
 
     // ---- 4. hash groups of 64 sorted strings ---------------------------------------------
     const uint32_t ngroups = (n_tile + 63u) >> 6;
@@ -149,6 +200,18 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) H[i] = vkmr_dev::IV256[i];
 
+        // Gather path (tile not staged): the wavefront fetches its 64 strings' blocks
+        // cooperatively -- 16 lanes read the 64 contiguous bytes of one string's block, 4
+        // strings per load instruction -- through this wavefront's private LDS rows, so
+        // HBM/L2 see 64-byte segments instead of 64 scattered dwords per instruction.
+        const uint32_t sub = lane >> 4, wi = lane & 15u;
+        uint32_t* wl = s_stage + (tid >> 6) * (64u * VKMR_MAP_GATHER_STRIDE);
+        uint32_t gstart[GATHER ? 16 : 1];
+        if (GATHER && !staged) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gstart[GATHER ? j : 0] = __shfl(start, 4 * j + (int)sub);
+        }
+
         for (uint32_t b = 0; __any(b < nb); ++b) {
             uint32_t w[16];
             // raw words of this block (garbage beyond the string is masked below)
@@ -157,28 +220,61 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
                 base = base < span ? base : span;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) w[i] = s_stage[base + i];
-            } else {
+            } else if (!GATHER) {
+                // per lane, straight from HBM/L2: four 16-byte loads (strings are only 4-byte
+                // aligned; gfx950 takes dword-aligned dwordx4), scalar loads at the buffer's end
                 const uint64_t gbase = (uint64_t)start + ((uint64_t)b << 4);
+                if (gbase + 16u <= data_words) {
+                    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4_u* src = reinterpret_cast<const u32x4_u*>(data + gbase);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint64_t idx = gbase + i;
-                    w[i] = (idx < data_words) ? data[idx] : 0u;
+                    for (int q = 0; q < 4; ++q) {
+                        const u32x4_u v = src[q];
+                        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint64_t idx = gbase + i;
+                        w[i] = (idx < data_words) ? data[idx] : 0u;
+                    }
+                }
+            } else {
+                uint32_t g[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t idx = (uint64_t)gstart[GATHER ? j : 0] + ((uint64_t)b << 4) + wi;
+                    g[j] = (idx < data_words) ? data[idx] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) wl[(4 * j + sub) * VKMR_MAP_GATHER_STRIDE + wi] = g[j];
+                const uint4* row = reinterpret_cast<const uint4*>(wl + lane * VKMR_MAP_GATHER_STRIDE);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 v = row[q];
+                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
                 }
             }
             // valid bytes of the string inside this block: 0..64
             const uint64_t boff = (uint64_t)b << 6;
             const uint32_t r = (boff >= size) ? 0u : ((size - boff >= 64u) ? 64u : (uint32_t)(size - boff));
-            const bool term_here = (boff <= size) && (size - boff < 64u);   // the 0x80 byte falls in this block
-            const uint32_t bw = term_here ? (r >> 2) : 16u;                 // word holding the terminator
-            const uint32_t kb = (r & 3u) << 3;
-            const uint32_t keep = kb ? (0xFFFFFFFFu << (32u - kb)) : 0u;
-            const uint32_t padbit = 0x80000000u >> kb;
-            const uint32_t full = r >> 2;                                   // whole data words
+            if (FULLFAST && __all(r == 64u || b >= nb)) {
+                // every string of the group still has 64 bytes here: plain byte swap
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t v = __builtin_bswap32(w[i]);
-                const uint32_t bnd = (v & keep) | padbit;
-                w[i] = ((uint32_t)i < full) ? v : (((uint32_t)i == bw) ? bnd : 0u);
+                for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(w[i]);
+            } else {
+                const bool term_here = (boff <= size) && (size - boff < 64u);   // the 0x80 byte falls in this block
+                const uint32_t bw = term_here ? (r >> 2) : 16u;                 // word holding the terminator
+                const uint32_t kb = (r & 3u) << 3;
+                const uint32_t keep = kb ? (0xFFFFFFFFu << (32u - kb)) : 0u;
+                const uint32_t padbit = 0x80000000u >> kb;
+                const uint32_t full = r >> 2;                                   // whole data words
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t v = __builtin_bswap32(w[i]);
+                    const uint32_t bnd = (v & keep) | padbit;
+                    w[i] = ((uint32_t)i < full) ? v : (((uint32_t)i == bw) ? bnd : 0u);
+                }
             }
             if (b + 1u == nb) {   // last block carries the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
                 w[14] = size >> 29;
@@ -192,6 +288,16 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
             vkmr_dev::store_node(out + tile_base + id, o);
         }
     }
+#ifdef VKMR_MAP_STAMPS
+    {
+        unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 32768u) {   // wavefront 0 of each workgroup: its own phase boundaries
+            unsigned long long* o = g_map_stamps + (size_t)blockIdx.x * 8;
+            o[0] = t_begin; o[1] = t_sorted; o[2] = t_staged; o[3] = t_end; o[4] = rt;
+        }
+    }
+#endif
 }
 
 // ============================================================================
@@ -440,9 +546,16 @@ extern "C" {
 
 const char* vkmr_hip_last_error(void) { return g_err; }
 
+#ifdef VKMR_MAP_STAMPS
+__attribute__((visibility("default"))) int vkmr_hip_debug_stamps(unsigned long long* out, int words)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_map_stamps), sizeof(unsigned long long) * words) == hipSuccess ? 0 : -1;
+}
+#endif
+
 const char* vkmr_hip_kernel_info(void)
 {
-    return "map=map_kernel(tile-sorted,LDS-staged) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
+    return "map=map_kernel(tile-sorted by block count, per-lane dwordx4 fetch) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
 }
 
 vkmr_status vkmr_hip_device_count(int* count)
@@ -641,26 +754,42 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     if (!meta_dev || !out_dev || (!data_dev && data_words != 0))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
     VKMR_TRY(hipSetDevice(dev));
-    // strings per tile: as many as are expected to fit the LDS staging area (64-string
-    // groups), at most MAX_TILE; long strings take full tiles and read HBM per lane
+    // VKMR_MAP_VARIANT picks an alternative fetch mode / geometry for A/B timing; 0 = shipped.
     static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
-    auto launch = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
+    Node* out = reinterpret_cast<Node*>(out_dev);
+    // staged mode: strings per tile = what is expected to fit the LDS staging area
+    auto launch_staged = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
         uint32_t tile = max_tile;
         if (avg_words > 0) {
             const uint64_t fit = (uint64_t)(stage_words * 0.9) / avg_words;
             if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
         }
-        const uint32_t grid = (count + tile - 1) / tile;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count,
-                           reinterpret_cast<Node*>(out_dev), tile);
+        hipLaunchKernelGGL(kern, dim3((count + tile - 1) / tile), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
     };
-    switch (variant) {   // VKMR_MAP_VARIANT selects an experimental geometry; 0 = the shipped one
-        case 1: launch(map_kernel<512, 1024, 16384>, 512, 1024, 16384); break;
-        case 2: launch(map_kernel<384, 768, 12288>, 384, 768, 12288); break;
-        case 3: launch(map_kernel<1024, 2048, 32768>, 1024, 2048, 32768); break;
-        case 4: launch(map_kernel<256, 1024, 16384>, 256, 1024, 16384); break;
-        default: launch(map_kernel<256, 512, 8192>, 256, 512, 8192); break;   // 4 workgroups/CU, 38 KiB LDS each
+    // tiles of up to 2048 strings, smaller when the batch is short so that it still
+    // spreads over the chip (>= ~1024 workgroups when it can)
+    uint32_t tile = (count / 1024u) & ~63u;
+    tile = tile < 256u ? 256u : (tile > 2048u ? 2048u : tile);
+    const uint32_t grid = (count + tile - 1) / tile;
+    switch (variant) {
+        case 1: launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384); break;     // LDS-staged tiles, 64 KiB
+        case 2: launch_staged(map_kernel<256, 512, 8192, 0>, 256, 512, 8192); break;         // LDS-staged tiles, 32 KiB
+        case 3: hipLaunchKernelGGL((map_kernel<256, 2048, 5120, 1, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev,
+                                   count, out, tile); break;                                 // per-wavefront gather through LDS
+        default:   // per-lane 16-byte loads; long strings (>= 128 B on average) get the full-block fast path
+            if (avg_words >= 32) {
+                if (tile >= 1024u)
+                    hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+                else
+                    hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+            } else {
+                if (tile >= 1024u)
+                    hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, false>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+                else
+                    hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, false>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+            }
+            break;
     }
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
