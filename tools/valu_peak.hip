@@ -31,7 +31,6 @@ __global__ __launch_bounds__(256) void spin(uint32_t* out, int iters)
                 if (KIND == 10) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
                 if (KIND == 11) asm volatile("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
                 if (KIND == 12) asm volatile("v_bfe_u32 %0, %1, 3, 9" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
-                if (KIND == 13) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
                 if (KIND == 14) asm volatile("v_alignbyte_b32 %0, %1, %2, 1" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
                 if (KIND == 15) asm volatile("v_pk_add_u16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
                 if (KIND == 16) asm volatile("v_lshrrev_b64 %0, 7, %1" : "=v"(*(unsigned long long*)&a[i & 6]) : "v"(*(unsigned long long*)&a[(i + 2) & 6]));
@@ -48,6 +47,16 @@ __global__ __launch_bounds__(256) void spin(uint32_t* out, int iters)
                 if (KIND == 29) asm volatile("v_add_co_u32 %0, vcc, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc");
                 if (KIND == 30) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
                 if (KIND == 31) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(unsigned long long*)&a[i & 6]) : "v"(*(unsigned long long*)&a[(i + 2) & 6]), "v"(*(unsigned long long*)&a[(i + 4) & 6]));
+                if (KIND == 32) asm volatile("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc");
+                if (KIND == 33) asm volatile("v_cmp_lt_u32_e64 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %1, %2, s[20:21]" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]) : "s20", "s21");
+                if (KIND == 34) asm volatile("v_and_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                if (KIND == 35) asm volatile("v_sub_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                if (KIND == 36) asm volatile("v_ashrrev_i32 %0, 7, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 37) asm volatile("v_min_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                if (KIND == 38) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc");
+                if (KIND == 39) asm volatile("v_or_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                if (KIND == 40) asm volatile("v_add_u32 %0, 0x428a2f98, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 41) asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]), "s"(iters));
                 if (KIND == 18) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
             }
         }
@@ -95,7 +104,6 @@ int main()
         run<10>("v_and_or_b32", blocks, 4000, d);
         run<11>("v_lshl_add_u32", blocks, 4000, d);
         run<12>("v_bfe_u32", blocks, 4000, d);
-        run<13>("v_cndmask_b32", blocks, 4000, d);
         run<14>("v_alignbyte_b32", blocks, 4000, d);
         run<15>("v_pk_add_u16", blocks, 4000, d);
         run<16>("v_lshrrev_b64", blocks, 4000, d);
@@ -113,6 +121,16 @@ int main()
         run<29>("v_add_co_u32", blocks, 4000, d);
         run<30>("v_mov_b32", blocks, 4000, d);
         run<31>("v_pk_add_f32", blocks, 4000, d);
+        run<32>("cmp_e32+cndmask_e32 (2 instr)", blocks, 4000, d);
+        run<33>("cmp_e64+cndmask_e64 (2 instr)", blocks, 4000, d);
+        run<34>("v_and_b32", blocks, 4000, d);
+        run<35>("v_sub_u32", blocks, 4000, d);
+        run<36>("v_ashrrev_i32", blocks, 4000, d);
+        run<37>("v_min_u32", blocks, 4000, d);
+        run<38>("v_cmp_lt_u32_e32", blocks, 4000, d);
+        run<39>("v_or_b32", blocks, 4000, d);
+        run<40>("v_add_u32 literal", blocks, 4000, d);
+        run<41>("v_bitop3 v,v,s", blocks, 4000, d);
     }
     for (int wavesPerSimd : {1, 2, 4, 8}) {
         int blocks = p.multiProcessorCount * wavesPerSimd;   // 256-thread blocks = 4 waves = 1 per SIMD

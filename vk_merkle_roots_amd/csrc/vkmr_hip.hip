@@ -32,16 +32,20 @@ using vkmr_dev::Node;
 //      16 message words per lane, byte swap, 0x80 / zero / bit-length padding by masks
 //      (no branches), 64 unrolled rounds with the schedule ring in VGPRs.
 // How the 16 words reach the lane is the template parameter MODE (all three are kept,
-// parity-tested and timed against each other; profiles/r01_map_fetch_modes.txt):
-//   MODE 2 (shipped)  four 16-byte loads per lane straight from HBM/L2 -- the strings of a
-//                     tile are contiguous, so the tile's lines are shared through L2 and
-//                     each 128-byte line is fetched from HBM once; no LDS, 7 waves/SIMD;
-//   MODE 0            the tile's packed bytes copied to LDS with coalesced 16-byte loads,
-//                     lanes read LDS (the layout the north star describes);
-//   MODE 1            per-wavefront gather: 16 lanes read one string's 64 contiguous
-//                     bytes, four strings per load, transposed through LDS rows.
-// The kernel is bound by VALU issue, not by bytes, and MODE 2 frees the LDS and the
-// wave slots the other two hold during staging, so it is the fastest of the three.
+// parity-tested and timed against each other: profiles/r01_map_fetch_modes.txt,
+// profiles/r01_map_fetch_vs_tile.txt):
+//   MODE 0  the tile's packed bytes are copied to LDS with coalesced 16-byte HBM loads and
+//           lanes read LDS (the layout the north star describes).  Shipped for short
+//           strings: every byte crosses the HBM interface exactly once.
+//   MODE 2  four 16-byte loads per lane straight from HBM/L2 (strings are 4-byte aligned;
+//           gfx950 takes dword-aligned dwordx4).  No LDS, 7 waves/SIMD.  Shipped for long
+//           strings (>= 128 B on average); for short ones it is 1-2 % faster than MODE 0 but
+//           a 128-byte line shared by strings of different block counts is used at different
+//           times and re-fetched once it has left L2 (1.6x the algorithmic bytes at L2/fabric).
+//   MODE 1  per-wavefront gather: 16 lanes read one string's 64 contiguous bytes, four
+//           strings per load, transposed through LDS rows.  Kept as the measured alternative.
+// The kernel is bound by VALU issue, not by bytes: the three modes are within 5 % of
+// each other.
 // Digest i lands in out[i] whatever the processing order.
 
 #define VKMR_MAP_STAGE_PAD 32
@@ -555,7 +559,7 @@ __attribute__((visibility("default"))) int vkmr_hip_debug_stamps(unsigned long l
 
 const char* vkmr_hip_kernel_info(void)
 {
-    return "map=map_kernel(tile-sorted by block count, per-lane dwordx4 fetch) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
+    return "map=map_kernel(tile-sorted by block count; LDS-staged tiles, per-lane dwordx4 for long strings) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
 }
 
 vkmr_status vkmr_hip_device_count(int* count)
@@ -771,24 +775,37 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     // spreads over the chip (>= ~1024 workgroups when it can)
     uint32_t tile = (count / 1024u) & ~63u;
     tile = tile < 256u ? 256u : (tile > 2048u ? 2048u : tile);
+    static const int tile_override = [] { const char* e = getenv("VKMR_MAP_TILE"); return e ? atoi(e) : 0; }();   // experiments only
+    if (tile_override >= 64 && tile_override <= 2048) tile = (uint32_t)tile_override & ~63u;
     const uint32_t grid = (count + tile - 1) / tile;
+    auto launch_direct = [&](bool fullfast) {
+        if (fullfast) {
+            if (tile >= 1024u)
+                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+            else
+                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        } else {
+            if (tile >= 1024u)
+                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, false>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+            else
+                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, false>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        }
+    };
     switch (variant) {
         case 1: launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384); break;     // LDS-staged tiles, 64 KiB
         case 2: launch_staged(map_kernel<256, 512, 8192, 0>, 256, 512, 8192); break;         // LDS-staged tiles, 32 KiB
         case 3: hipLaunchKernelGGL((map_kernel<256, 2048, 5120, 1, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev,
                                    count, out, tile); break;                                 // per-wavefront gather through LDS
-        default:   // per-lane 16-byte loads; long strings (>= 128 B on average) get the full-block fast path
-            if (avg_words >= 32) {
-                if (tile >= 1024u)
-                    hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-                else
-                    hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-            } else {
-                if (tile >= 1024u)
-                    hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, false>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-                else
-                    hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, false>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-            }
+        case 4: launch_direct(avg_words >= 32); break;                                       // per-lane 16-byte loads for every length
+        default:
+            // Shipped: short strings (< 128 B on average: a cache line holds several) go through
+            // LDS-staged tiles -- HBM traffic == algorithmic bytes; the per-lane mode is 1-2 %
+            // faster but re-reads lines that fell out of L2 (1.6x traffic, profiles/
+            // r01_map_fetch_modes.txt).  Long strings read per lane with the full-block fast path.
+            if (avg_words >= 32)
+                launch_direct(true);
+            else
+                launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384);
             break;
     }
     VKMR_TRY(hipGetLastError());
