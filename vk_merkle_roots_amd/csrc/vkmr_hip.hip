@@ -816,13 +816,13 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
 
 static inline uint64_t ceil_shift(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
 
-// Levels a bulk pass collapses for n input nodes: the largest m+1 (m <= MAXM) that
-// still leaves enough wavefronts to fill 256 CUs.
-static uint32_t pick_m(uint64_t n)
+// Levels a bulk pass collapses for n input nodes per slice: the largest m+1 (m <= MAXM)
+// that still leaves enough wavefronts (over all slices of the launch) to fill 256 CUs.
+static uint32_t pick_m(uint64_t n, uint32_t nslices)
 {
     const uint64_t target_waves = 4096;
     for (int m = VKMR_PASS_MAXM; m > 0; --m)
-        if (ceil_shift(n, 7 + m) >= target_waves) return (uint32_t)m;
+        if (ceil_shift(n, 7 + m) * nslices >= target_waves && (128ull << m) <= n) return (uint32_t)m;
     return 0;
 }
 
@@ -840,28 +840,34 @@ static bool height_ok(uint64_t count, uint32_t height)
 struct ReduceStep { int kind; uint32_t levels; uint64_t n_out; };
 enum { STEP_BULK = 0, STEP_COLLAPSE = 1, STEP_TAIL = 2 };
 
-static ReduceStep next_step(uint64_t n, uint32_t left)
+static ReduceStep next_step(uint64_t n, uint32_t left, uint32_t nslices)
 {
     ReduceStep st;
     if (n <= 128) {
         st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
-    } else if (ceil_shift(n, 7) >= 2048) {
-        st.kind = STEP_BULK; st.levels = pick_m(n) + 1u; st.n_out = ceil_shift(n, st.levels);
+    } else if (ceil_shift(n, 7) * nslices >= 2048) {
+        st.kind = STEP_BULK; st.levels = pick_m(n, nslices) + 1u; st.n_out = ceil_shift(n, st.levels);
     } else {
         st.kind = STEP_COLLAPSE; st.levels = 7; st.n_out = ceil_shift(n, 7);
     }
     return st;
 }
 
+// Scratch cells one slice needs when `nslices` slices are reduced together.
+static uint64_t scratch_cells(uint64_t count, uint32_t nslices)
+{
+    uint64_t n = count, total = 0;
+    for (int pass = 0; pass < 2 && n > 128; ++pass) {
+        n = next_step(n, 64, nslices).n_out;
+        total += n;
+    }
+    return total + 2;
+}
+
 size_t vkmr_hip_reduce_scratch_bytes(uint64_t count)
 {
     // ping-pong: outputs of step 1 and step 2 (later steps are smaller)
-    uint64_t n = count, total = 0;
-    for (int pass = 0; pass < 2 && n > 128; ++pass) {
-        n = next_step(n, 64).n_out;
-        total += n;
-    }
-    return (size_t)(total + 2) * sizeof(vkmr_digest);
+    return (size_t)scratch_cells(count, 1) * sizeof(vkmr_digest);
 }
 
 // Reduces `nslices` slices (n_full nodes each, the last n_last) through `height`
@@ -876,7 +882,7 @@ static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32
     Node* bufA = scratch;
     Node* bufB = nullptr;
     for (int pass = 0;; ++pass) {
-        const ReduceStep st = next_step(n, left);
+        const ReduceStep st = next_step(n, left, nslices);
         SliceGeom g;
         g.n_full = n; g.n_last = nl; g.in_stride = in_stride; g.nslices = nslices;
         if (st.kind == STEP_TAIL) {
@@ -926,7 +932,8 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* dig
 
 size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
 {
-    return vkmr_hip_reduce_scratch_bytes(capacity) * (size_t)(nslices ? nslices : 1);
+    if (nslices == 0) nslices = 1;
+    return (size_t)scratch_cells(capacity, nslices) * nslices * sizeof(vkmr_digest);
 }
 
 vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint32_t nslices,
