@@ -236,11 +236,15 @@ def main():
         blocks = int(((sizes + 8) // 64 + 1).sum())
         map_ops = blocks * 2532 + n * 2093
         red_ops = (n - nslices) * 5685
+        # HBM bytes per map launch from the PMC passes of the SAME launch shape (profiles/pmc_latest.json,
+        # written by tools/pmc_profile.sh + tools/pmc_to_json.py on the GPU box); null when none matches
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("map_kernel_hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("strings_per_map_launch") == bstr and rec.get("maxlen") == a.maxlen and not os.environ.get("VKMR_MAP_VARIANT"):
+                    traffic = rec.get("map_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
