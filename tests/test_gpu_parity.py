@@ -77,6 +77,35 @@ def test_map_rndm_batches(gpu, oracle, seed, count, maxlen):
     assert (got == want).all()
 
 
+def test_map_metadata_in_any_order(gpu, oracle):
+    """The ABI takes any metadata, not only Batch::Push's ascending layout: permuted entries,
+    entries sharing bytes, a tile whose strings are far apart (falls off the staged path)."""
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(31, 5000, 127)
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(5000)
+    meta = b.meta[perm].copy()
+    meta = np.concatenate([meta, meta[:100]])            # duplicates: same bytes hashed twice
+    shuffled = vk.PackedBatch(b.data, meta, b.words, 0)
+    got = gpu.leaf_digests(shuffled)
+    want = oracle.leaves_packed(b.data, meta)
+    assert (got == want).all()
+
+
+def test_map_out_of_range_metadata_does_not_fault(gpu, oracle):
+    """A start/size pointing past data_words must not read out of bounds: missing words hash as zeros."""
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(32, 1000, 127)
+    meta = b.meta.copy()
+    meta[10] = (b.words - 1, 64)            # runs 15 words past the end
+    meta[20] = (b.words + 1000, 5)          # entirely outside
+    meta[999] = (b.words - 2, 200)
+    got = gpu.leaf_digests(vk.PackedBatch(b.data, meta, b.words, 0))
+    padded = np.concatenate([b.data, np.zeros(2000, dtype=np.uint32)])
+    want = oracle.leaves_packed(padded, meta)
+    assert (got == want).all()
+
+
 def test_map_into_sub_slice_offsets(gpu, oracle):
     """Two batches mapped into one slice at different offsets (Slice::Sub, reference Slices.h:145-187)."""
     import vk_merkle_roots_amd as vk
