@@ -309,7 +309,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "leaf hashes/sec (SHA-256d) + Merkle-root wall time",
+            "metric": "leaf hashes/sec (SHA-256d) + Merkle-root wall time, 2^26 leaves, 1/2/4/8 GPU",
             "value": value, "unit": "leaf hashes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -160,6 +160,25 @@ VKMR_API vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s,
 VKMR_API size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices);
 
 /*
+ * PROOF (the reference's own "to do", README.md:118-120): the authentication path of
+ * leaf `index` in exactly the tree vkmr_hip_reduce_async(count, height) computes.
+ * siblings_dev[l], l = 0..height-1, receives the node the path node is hashed with at
+ * level l: its left or right neighbour (bit l of `index` says which side the path node
+ * is on: 0 = path node left), or the path node itself where it has no right sibling
+ * (duplicate-last rule).  Folding the leaf digest with the siblings from l = 0 upwards
+ * gives the root, which is also written to root_dev (may be NULL).  For a stream that
+ * spans several slices the caller chains two proofs: this one inside the slice
+ * (height = log2 capacity) and one over the slice roots.  Each sibling is the root of
+ * the neighbouring sub-tree of 2^l leaves and is computed with the same kernels as the
+ * reduction (total work: about one more reduction of the slice).
+ * scratch_dev: vkmr_hip_reduce_scratch_bytes(count) bytes.
+ */
+VKMR_API vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s,
+                                          const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
+                                          uint64_t index, void* scratch_dev,
+                                          vkmr_digest* siblings_dev, vkmr_digest* root_dev);
+
+/*
  * One tree level per launch, one lane per pair: the reference's non-subgroup
  * reduction (BasicReduction, src/vkmr/Reductions.cpp:257-409; shader :393-434).
  * Kept as an independent cross-check of vkmr_hip_reduce_async; same contract.

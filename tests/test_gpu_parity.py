@@ -227,3 +227,48 @@ def test_ragged_multi_slice(gpu, oracle):
         want = oracle.hex(oracle.root(oracle.leaves_packed(b.data, b.meta)))
         assert vk.merkle_root_packed(gpu, b) == want
         assert vk.merkle_root_packed(gpu, b, slice_capacity=1024, batch_strings=300) == want
+
+
+# ---- proofs (the reference's to-do, README.md:118-120) -------------------------------------
+
+def test_proofs_fold_to_the_root(gpu, oracle):
+    """Every sibling equals the oracle's node at that level, and folding reproduces the root."""
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    rng = np.random.default_rng(12)
+    for n, height in [(1, 1), (2, 1), (3, 2), (5, 3), (8, 3), (9, 4), (100, 7), (129, 8), (1000, 10), (1000, 14), (4097, 13),
+                      (70001, 17), (300000, 19)]:
+        leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+        # oracle levels
+        levels = [leaves]
+        for _ in range(height):
+            cur = levels[-1]
+            nxt = None
+            if len(cur) <= 4096:
+                nxt = np.stack([oracle.node(cur[2 * p], cur[2 * p + 1] if 2 * p + 1 < len(cur) else cur[2 * p])
+                                for p in range((len(cur) + 1) // 2)])
+            if nxt is None:
+                break
+            levels.append(nxt)
+        want_root = oracle.reduce_height(leaves, height)
+        d_in = gpu.upload(leaves)
+        for index in sorted({0, n - 1, n // 2, (n * 2) // 3, max(0, n - 2)}):
+            sib, root = gpu.proof(d_in, n, height, index)
+            assert (root == want_root).all(), (n, height, index)
+            folded = np.zeros(8, dtype=np.uint32)
+            h.vkmr_host_cpu_fold_proof(leaves[index].ctypes.data, index, np.ascontiguousarray(sib).ctypes.data, height, folded.ctypes.data)
+            assert (folded == want_root).all(), (n, height, index)
+            if len(levels) == height + 1:      # small case: check each sibling against the oracle's level arrays
+                for l in range(height):
+                    p = index >> l
+                    q = p ^ 1
+                    if q >= len(levels[l]):
+                        q = p
+                    assert (sib[l] == levels[l][q]).all(), (n, height, index, l)
+
+
+def test_proof_rejects_bad_index(gpu):
+    import vk_merkle_roots_amd as vk
+    d = gpu.alloc(32 * 8)
+    with pytest.raises(vk.VkmrError):
+        gpu.proof(d, 8, 3, 8)

@@ -49,6 +49,8 @@ SIGNATURES = {
     "vkmr_hip_reduce_slices_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                                C.c_void_p, C.c_void_p]),
     "vkmr_hip_reduce_slices_scratch_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32]),
+    "vkmr_hip_proof_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "vkmr_hip_reduce_levels_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_reduce_levels_scratch_bytes": (C.c_size_t, [C.c_uint64]),
     "vkmr_hip_combine": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -61,6 +63,7 @@ HOST_SIGNATURES = {
     "vkmr_host_cpu_leaves": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "vkmr_host_cpu_reduce": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "vkmr_host_cpu_combine": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vkmr_host_cpu_fold_proof": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vkmr_host_rndm_pack": (C.c_int64, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                         C.POINTER(C.c_uint64)]),
     "vkmr_host_rndm_rand": (None, [C.c_uint32, C.c_void_p, C.c_uint64]),

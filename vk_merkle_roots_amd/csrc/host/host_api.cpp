@@ -55,4 +55,23 @@ __attribute__((visibility("default"))) int vkmr_host_cpu_combine(const vkmr_dige
     return 0;
 }
 
+// Folds a leaf digest with the siblings of its authentication path (vkmr_hip_proof_async):
+// bit l of `index` tells whether the path node is the right (1) or left (0) operand at level l.
+__attribute__((visibility("default"))) void vkmr_host_cpu_fold_proof(const vkmr_digest* leaf, uint64_t index, const vkmr_digest* siblings,
+                                                                      uint32_t height, vkmr_digest* root)
+{
+    uint32_t cur[8];
+    std::memcpy(cur, leaf->data, 32);
+    for (uint32_t l = 0; l < height; ++l) {
+        uint32_t next[8];
+        const bool right = (l < 64) && ((index >> l) & 1ull);
+        if (right)
+            vkmr::cpu_sha256d_pair(siblings[l].data, cur, next);
+        else
+            vkmr::cpu_sha256d_pair(cur, siblings[l].data, next);
+        std::memcpy(cur, next, 32);
+    }
+    std::memcpy(root->data, cur, 32);
+}
+
 }  // extern "C"

@@ -930,6 +930,39 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* dig
                          reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
 }
 
+// ---- proof ----------------------------------------------------------------------
+
+vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
+                                 uint64_t index, void* scratch_dev, vkmr_digest* siblings_dev, vkmr_digest* root_dev)
+{
+    if (!digests_dev || !siblings_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null pointer");
+    if (!height_ok(count, height)) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: height does not reduce count to one node");
+    if (index >= count) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: index out of range");
+    if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null scratch");
+    VKMR_TRY(hipSetDevice(dev));
+    const Node* leaves = reinterpret_cast<const Node*>(digests_dev);
+    Node* sib = reinterpret_cast<Node*>(siblings_dev);
+    for (uint32_t l = 0; l < height; ++l) {
+        // level l has cl nodes; the path node is p, its partner q (or p itself at the ragged right edge)
+        const uint64_t cl = (l >= 64) ? 1 : ceil_shift(count, l);
+        const uint64_t p = (l >= 64) ? 0 : (index >> l);
+        uint64_t q = p ^ 1ull;
+        if (q >= cl) q = p;
+        // node q of level l = root of the sub-tree over leaves [q * 2^l, min((q + 1) * 2^l, count)), l levels
+        const uint64_t lo = (l >= 64) ? 0 : (q << l);
+        uint64_t n = (l >= 63) ? count - lo : ((count - lo < (1ull << l)) ? count - lo : (1ull << l));
+        if (l == 0) {
+            VKMR_TRY(hipMemcpyAsync(sib, leaves + lo, sizeof(Node), hipMemcpyDeviceToDevice, S(s)));
+        } else {
+            const vkmr_status st = reduce_launch(S(s), leaves + lo, 1, n, n, l, reinterpret_cast<Node*>(scratch_dev), sib + l);
+            if (st != VKMR_OK) return st;
+        }
+    }
+    if (root_dev)
+        return reduce_launch(S(s), leaves, 1, count, count, height, reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
+    return VKMR_OK;
+}
+
 size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
 {
     if (nslices == 0) nslices = 1;

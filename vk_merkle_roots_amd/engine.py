@@ -179,6 +179,19 @@ class HipDevice:
                                                     height, scratch_buf.ptr if scratch_buf else None, roots_buf.ptr),
               "vkmr_hip_reduce_slices_async")
 
+    def proof(self, digests_buf, count, height, index):
+        """(siblings [height, 8], root [8]) of leaf `index` in the tree reduce_async(count, height) computes."""
+        d_sib = self.alloc(32 * max(height, 1))
+        d_root = self.alloc(32)
+        d_scratch = self.reduce_scratch(count)
+        check(self.lib.vkmr_hip_proof_async(self.index, self.stream, digests_buf.ptr, count, height, index, d_scratch.ptr, d_sib.ptr,
+                                            d_root.ptr), "vkmr_hip_proof_async")
+        sib = self.download(d_sib, 32 * height).reshape(-1, 8) if height else np.zeros((0, 8), np.uint32)
+        root = self.download(d_root, 32)
+        for b in (d_sib, d_root, d_scratch):
+            b.free()
+        return sib, root
+
     def reduce_scratch(self, count, levels_variant=False):
         fn = self.lib.vkmr_hip_reduce_levels_scratch_bytes if levels_variant else self.lib.vkmr_hip_reduce_scratch_bytes
         return self.alloc(fn(count))
