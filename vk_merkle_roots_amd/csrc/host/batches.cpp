@@ -60,6 +60,19 @@ bool Batch::Push(const std::vector<std::string>& strings)
     return true;
 }
 
+PackResult Batch::PushLines(const char* buf, size_t len, bool final, size_t max_strings)
+{
+    PackResult r = {0, 0, 0, 0, 0};
+    if (!(*this)) return r;
+    size_t room = m_cap_count - m_count;
+    if (room > max_strings) room = max_strings;
+    r = PackLines(reinterpret_cast<const uint8_t*>(buf), len, final, m_data, m_words, m_cap_words, m_meta + m_count, room);
+    m_count += r.strings;
+    m_words += r.words;
+    m_bytes += r.bytes;
+    return r;
+}
+
 void Batch::Pop(size_t count)
 {
     while (count-- && m_count) {

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "stream_pack.hpp"
 #include "vkmr_hip.h"
 
 namespace vkmr {
@@ -47,6 +48,10 @@ public:
     // is unchanged).  Reference Batch::Push, src/vkmr/Batches.cpp:64-121.
     bool Push(const char* p, size_t n);
     bool Push(const std::vector<std::string>& strings);
+    // Packs the non-empty lines of buf[0,len) straight into the pinned buffers, at most
+    // `max_strings`; stops early when the batch is full.  Returns what PackLines reports
+    // (bytes consumed, strings appended, ...).
+    struct PackResult PushLines(const char* buf, size_t len, bool final, size_t max_strings);
     // Drops the last `count` strings (reference Batch::Pop, src/vkmr/Batches.cpp:123-125).
     void Pop(size_t count);
 

@@ -6,6 +6,7 @@
 #include "hip_sha256d.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 #include "util.hpp"
@@ -166,6 +167,49 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
         }
     }
     return m_slices.Current().Reserve(1);
+}
+
+// Bulk ingest: whole spans of lines are packed straight into the pinned batch
+// (memchr + memcpy per line, no per-line call or temporary), with the same batch/slice
+// hand-offs as Add().
+bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tally* tally)
+{
+    if (!m_ok) return false;
+    size_t pos = 0;
+    while (pos < len) {
+        m_reductions->Update();
+        if (m_mappings->InFlight()) Account(m_mappings->Update());
+        if (!m_slices.Current()) {
+            if (!StartSliceAndBatch()) return (m_ok = false);
+        } else if (m_slices.Current().Available() == 0) {
+            if (!MapCurrent() || !StartSliceAndBatch()) return (m_ok = false);
+        }
+        Slice& slice = m_slices.Current();
+        const PackResult r = m_batch.PushLines(buf + pos, len - pos, final, slice.Available());
+        slice.Reserve(r.strings);
+        tally->items += r.strings;
+        tally->bytes += r.bytes;
+        tally->empties += r.empties;
+        pos += r.consumed;
+        if (pos >= len) break;
+        if (slice.Available() == 0) continue;            // slice full: the loop head opens the next one
+        if (r.strings == 0 && r.consumed == 0) {
+            if (!final && !memchr(buf + pos, '\n', len - pos)) break;   // only an incomplete line is left
+            // the batch is full (or the next line does not fit): map it, continue in a fresh one
+            const int dev = slice.Device();
+            const bool was_empty = m_batch.Empty();
+            if (!MapCurrent()) return (m_ok = false);
+            m_batch = Dev(dev).batches->New();
+            if (!m_batch) return (m_ok = false);
+            if (was_empty) {   // even an empty batch cannot take the next line
+                const char* nl = static_cast<const char*>(memchr(buf + pos, '\n', len - pos));
+                std::cerr << "A string of " << (nl ? (size_t)(nl - (buf + pos)) : len - pos)
+                          << " byte(s) does not fit an empty batch." << std::endl;
+                return false;
+            }
+        }
+    }
+    return true;
 }
 
 ISha256D::out_type HipSha256D::Instance::Root()

@@ -47,6 +47,7 @@ public:
     out_type Root() override;
     bool Add(const arg_type& arg) override { return Add(arg.data(), arg.size()); }
     bool Add(const char* bytes, size_t size) override;
+    bool AddLines(const char* buf, size_t len, bool final, Tally* tally) override;
     bool Reset() override { return false; }   // reference IVkSha256DInstance::Reset, SHA-256vk.h:28
 
     bool Ok() const { return m_ok; }

@@ -59,6 +59,37 @@ bool Input::GetView(const char** p, size_t* n)
     return true;
 }
 
+bool Input::GetBlock(const char** p, size_t* n, bool* final)
+{
+    // keep the unconsumed tail (an incomplete line) at the front, then read more behind it
+    if (m_pos > 0 && m_pos < m_end) memmove(m_buf.data(), m_buf.data() + m_pos, m_end - m_pos);
+    m_end -= m_pos;
+    m_pos = 0;
+    for (;;) {
+        if (m_end == m_buf.size()) m_buf.resize(m_buf.size() * 2);   // a line longer than the buffer
+        const size_t got = m_fp ? fread(m_buf.data() + m_end, 1, m_buf.size() - m_end, m_fp) : 0;
+        m_end += got;
+        if (got == 0) {   // end of stream: everything left is the final span
+            *p = m_buf.data();
+            *n = m_end;
+            *final = true;
+            m_pos = m_end;
+            m_eof = true;
+            return true;
+        }
+        // last '\n' in the buffer (search backwards from the end)
+        size_t cut = m_end;
+        while (cut > 0 && m_buf[cut - 1] != '\n') --cut;
+        if (cut > 0) {
+            *p = m_buf.data();
+            *n = cut;
+            *final = false;
+            m_pos = cut;
+            return true;
+        }
+    }
+}
+
 std::string Input::Get()
 {
     const char* p = nullptr;

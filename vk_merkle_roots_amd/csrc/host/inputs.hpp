@@ -29,6 +29,10 @@ public:
     std::string Get();
     // Zero-copy form of Get(): pointer/length stay valid until the next call.
     bool GetView(const char** p, size_t* n);
+    // Bulk form: the next run of COMPLETE lines (each ending in '\n') as one span, or -- at the
+    // end of the stream -- whatever is left, with *final set (the last line then needs no
+    // '\n').  After the final span Has() is false.  Lines longer than the buffer grow it.
+    bool GetBlock(const char** p, size_t* n, bool* final);
 
     size_type Size() const { return m_size; }
     size_type Count() const { return m_count; }

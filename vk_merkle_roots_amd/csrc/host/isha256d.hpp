@@ -3,6 +3,7 @@
 // Same shape as the reference's vkmr::ISha256D (src/vkmr/ISha256D.h:18-37): a named
 // backend that accepts strings one at a time and returns the hex Merkle root.
 #pragma once
+#include <cstring>
 #include <string>
 
 namespace vkmr {
@@ -26,8 +27,34 @@ public:
     virtual bool Add(const char* bytes, size_t size) { return Add(arg_type(bytes, size)); }
     virtual bool Reset() = 0;
 
+    // Bulk form of the input loop's body: every non-empty line of buf[0,len) is added (a
+    // line ends at '\n'; when `final`, the last line may end at len).  Counts what was added
+    // and how many empty lines were skipped.  false = an Add was refused; lines before it
+    // were added.  The default walks the span line by line.
+    struct Tally { size_t items = 0, bytes = 0, empties = 0; };
+    virtual bool AddLines(const char* buf, size_t len, bool final, Tally* tally);
+
 protected:
     name_type m_name;
 };
+
+inline bool ISha256D::AddLines(const char* buf, size_t len, bool final, Tally* tally)
+{
+    size_t pos = 0;
+    while (pos < len) {
+        const char* nl = static_cast<const char*>(memchr(buf + pos, '\n', len - pos));
+        if (!nl && !final) break;
+        const size_t end = nl ? (size_t)(nl - buf) : len;
+        if (end == pos) {
+            ++tally->empties;
+        } else {
+            if (!Add(buf + pos, end - pos)) return false;
+            ++tally->items;
+            tally->bytes += end - pos;
+        }
+        pos = nl ? end + 1 : end;
+    }
+    return true;
+}
 
 }  // namespace vkmr

@@ -20,17 +20,20 @@ static int run(vkmr::ISha256D& backend)
     size_t size = 0, count = 0;
     vkmr::StopWatch sw;
     sw.Start();
-    while (input.Has()) {
+    bool refused = false;
+    while (input.Has() && !refused) {
         const char* p = nullptr;
         size_t n = 0;
-        input.GetView(&p, &n);
-        if (n == 0) {
-            std::cerr << "Read an empty string?" << std::endl;
-            continue;
-        }
-        if (!backend.Add(p, n)) break;
-        size += n;
-        ++count;
+        bool final = false;
+        input.GetBlock(&p, &n, &final);
+        vkmr::ISha256D::Tally tally;
+        refused = !backend.AddLines(p, n, final, &tally);
+        // the reference reads one more, empty, string when the stream ends right after a '\n'
+        // (or is empty): Input::Has is "not at EOF yet" (src/vkmr/Inputs.cpp:52-54)
+        if (final && !refused && (n == 0 || p[n - 1] == '\n')) ++tally.empties;
+        for (size_t i = 0; i < tally.empties; ++i) std::cerr << "Read an empty string?" << std::endl;
+        size += tally.bytes;
+        count += tally.items;
     }
     if (count > 0) {
         const std::string root = backend.Root();
