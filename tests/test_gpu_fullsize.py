@@ -74,3 +74,35 @@ def test_config5_long_strings(gpu, oracle):
     want = oracle.leaves_packed(batch.data, batch.meta, threads=64)
     assert (got == want).all()
     assert vk.merkle_root_packed_batched(gpu, batch, slice_capacity=1 << 16, batch_strings=1 << 15) == oracle.hex(oracle.root(want, threads=64))
+
+
+def test_config5_full_2p24_x_4k(gpu, oracle):
+    """BASELINE configs[4] at full size: rndm <seed> 2^24 4096 (about 34 GB of input, 1..65 blocks per
+    string), streamed as 16 batches of 2^20 strings (a packed batch addresses at most 2^32 words) into 2
+    slices of 2^23 (the reference's slice); every leaf digest and the root against the threaded oracle."""
+    import vk_merkle_roots_amd as vk
+    from vk_merkle_roots_amd.engine import digest_hex
+    n, per = 1 << 24, 1 << 20
+    stream = vk.RndmStream(5, 4096)
+    d_digests = gpu.alloc(32 * n)
+    want = np.zeros((n, 8), dtype=np.uint32)
+    total_bytes = 0
+    for b0 in range(0, n, per):
+        batch = stream.next(per)
+        total_bytes += batch.nbytes
+        d_data, d_meta = gpu.upload(batch.data), gpu.upload(batch.meta)
+        gpu.map_async(d_data, batch.words, d_meta, per, d_digests, out_offset_digests=b0)
+        want[b0: b0 + per] = oracle.leaves_packed(batch.data, batch.meta, threads=64)   # CPU checks while the GPU maps
+        gpu.sync()
+        d_data.free()
+        d_meta.free()
+    stream.close()
+    assert total_bytes > 30e9
+    got = gpu.download(d_digests, 32 * n).reshape(-1, 8)
+    assert (got == want).all()
+    del got
+    d_scratch = gpu.alloc(gpu.lib.vkmr_hip_reduce_slices_scratch_bytes(1 << 23, 2))
+    d_roots, d_top, d_final = gpu.alloc(64), gpu.reduce_scratch(2), gpu.alloc(32)
+    gpu.reduce_slices_async(d_digests, 2, 1 << 23, 1 << 23, 23, d_scratch, d_roots)
+    gpu.reduce_async(d_roots, 2, 1, d_top, d_final)
+    assert digest_hex(gpu.download(d_final, 32)) == oracle.hex(oracle.root(want, threads=64))

@@ -62,3 +62,16 @@ def test_batch_slice_rebases_metadata(native):
         st0, sz0 = b.meta[10 + i]
         assert sz == sz0
         assert s.data[st: st + (sz + 3) // 4].tolist() == b.data[st0: st0 + (sz0 + 3) // 4].tolist()
+
+
+def test_rndm_stream_batches_equal_one_shot(native):
+    import vk_merkle_roots_amd as vk
+    whole = vk.rndm_packed(13, 3000, 300)
+    st = vk.RndmStream(13, 300)
+    parts = [st.next(1000), st.next(1500), st.next(500)]
+    st.close()
+    lo = 0
+    for p in parts:
+        ref = whole.slice(lo, lo + p.count)
+        assert (p.meta == ref.meta).all() and (p.data == ref.data).all()
+        lo += p.count

@@ -8,4 +8,4 @@ hash on the CPU; without the built HIP extension every entry point raises.
 """
 from . import build  # noqa: F401
 from ._abi import Digest, Metadata, VkmrError, check, host_lib, lib  # noqa: F401
-from .engine import HipDevice, PackedBatch, merkle_root_packed, merkle_root_packed_batched, pack_lines, rndm_packed, tree_height  # noqa: F401
+from .engine import HipDevice, PackedBatch, RndmStream, merkle_root_packed, merkle_root_packed_batched, pack_lines, rndm_packed, tree_height  # noqa: F401

@@ -66,6 +66,9 @@ HOST_SIGNATURES = {
     "vkmr_host_cpu_fold_proof": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vkmr_host_rndm_pack": (C.c_int64, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                         C.POINTER(C.c_uint64)]),
+    "vkmr_host_rndm_open": (C.c_void_p, [C.c_uint32]),
+    "vkmr_host_rndm_close": (None, [C.c_void_p]),
+    "vkmr_host_rndm_next": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
     "vkmr_host_rndm_rand": (None, [C.c_uint32, C.c_void_p, C.c_uint64]),
     "vkmr_host_pack_lines": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

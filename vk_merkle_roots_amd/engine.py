@@ -75,6 +75,29 @@ def rndm_packed(seed, count, maxlen):
     return PackedBatch(data[: words.value], meta, words.value, int(meta[:, 1].astype(np.uint64).sum()))
 
 
+class RndmStream:
+    """The stream of `rndm seed * maxlen`, handed out as consecutive packed batches."""
+
+    def __init__(self, seed, maxlen):
+        self.h = _abi.host_lib()
+        self.maxlen = maxlen
+        self.handle = self.h.vkmr_host_rndm_open(seed)
+
+    def next(self, count):
+        cap = int(count) * ((self.maxlen - 2) // 4 + 1) + 4
+        data = np.empty(cap, dtype=np.uint32)
+        meta = np.empty((count, 2), dtype=np.uint32)
+        words = C.c_uint64(0)
+        if self.h.vkmr_host_rndm_next(self.handle, count, self.maxlen, data.ctypes.data, cap, meta.ctypes.data, C.byref(words)) != count:
+            raise RuntimeError("RndmStream.next: batch exceeds 2^32 words")
+        return PackedBatch(data[: words.value], meta, words.value, int(meta[:, 1].astype(np.uint64).sum()))
+
+    def close(self):
+        if self.handle:
+            self.h.vkmr_host_rndm_close(self.handle)
+            self.handle = None
+
+
 class DeviceBuffer:
     def __init__(self, dev, nbytes):
         self.dev = dev
