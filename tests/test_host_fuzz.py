@@ -1,0 +1,67 @@
+"""Host-side robustness: random streams through the front end's line rules and CPU backend versus the
+oracle (hypothesis), and the same front end built with AddressSanitizer + UBSan (CPU build only)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from conftest import ROOT
+
+ALPHABET = [b"a", b"b", b"\r", b"\n", b"\n", b"\xff", b"\x00", b" "]
+
+
+@settings(max_examples=120, deadline=None)
+@given(st.lists(st.sampled_from(ALPHABET), max_size=200), st.integers(0, 3))
+def test_pack_lines_and_cpu_backend_match_oracle(native, oracle, parts, reps):
+    import vk_merkle_roots_amd as vk
+    stream = b"".join(parts) * (reps + 1)
+    want_root, want_count, want_bytes = oracle.root_of_stream(stream)
+    b = vk.pack_lines(stream)
+    assert (b.count, b.nbytes) == (want_count, want_bytes)
+    if b.count == 0:
+        return
+    h = vk.host_lib()
+    leaves = np.zeros((b.count, 8), dtype=np.uint32)
+    h.vkmr_host_cpu_leaves(b.data.ctypes.data, b.meta.ctypes.data, b.count, leaves.ctypes.data)
+    top = np.zeros(8, dtype=np.uint32)
+    assert h.vkmr_host_cpu_combine(leaves.ctypes.data, b.count, top.ctypes.data) == 0
+    assert vk.engine.digest_hex(top) == want_root
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.lists(st.binary(min_size=0, max_size=300).filter(lambda s: b"\n" not in s), min_size=0, max_size=40), st.booleans())
+def test_vkmr_cpu_binary_matches_oracle(native, oracle, lines, trailing_newline):
+    stream = b"\n".join(lines) + (b"\n" if trailing_newline else b"")
+    want_root, want_count, want_bytes = oracle.root_of_stream(stream)
+    exe = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "vkmr")
+    r = subprocess.run([exe, "CPU"], input=stream, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    out = [l for l in r.stdout.decode().splitlines() if "computed root" in l]
+    if want_count == 0:
+        assert not out
+    else:
+        assert f"(of {want_count} item(s), {want_bytes} byte(s)) => {want_root} in " in out[0]
+
+
+def test_front_end_under_asan_ubsan(native, oracle, tmp_path):
+    """The whole host front end ("CPU" backend) compiled with -fsanitize=address,undefined."""
+    host = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc", "host")
+    libdir = os.path.dirname(native.HIP_LIB)
+    exe = str(tmp_path / "vkmr_asan")
+    srcs = [os.path.join(host, f) for f in ("vkmr_main.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "inputs.cpp", "batches.cpp",
+                                            "slices.cpp", "mappings.cpp", "reductions.cpp", "stream_pack.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "include"), "-I", host, "-o", exe] + srcs +
+                          ["-L", libdir, "-lvkmr_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    rng = np.random.default_rng(3)
+    streams = [b"", b"\n", b"a", b"a\nb\r\n\n\nccc", b"x" * 3000000 + b"\n" + b"y" * 10 + b"\n" + b"z" * 2500000,
+               b"\n".join(rng.integers(32, 126, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(0, 400, size=3000))]
+    for s in streams:
+        r = subprocess.run([exe, "CPU"], input=s, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        want_root, want_count, _ = oracle.root_of_stream(s)
+        out = [l for l in r.stdout.decode().splitlines() if "computed root" in l]
+        assert (not out) if want_count == 0 else (want_root in out[0])
