@@ -582,7 +582,8 @@ vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen)
     if (!buf || buflen == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_name: null buffer");
     hipDeviceProp_t p;
     VKMR_TRY(hipGetDeviceProperties(&p, dev));
-    snprintf(buf, buflen, "%s", p.name);
+    // some ROCm installs leave the marketing name empty: fall back to the ISA name
+    snprintf(buf, buflen, "%s", p.name[0] ? p.name : p.gcnArchName);
     return VKMR_OK;
 }
 
