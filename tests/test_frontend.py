@@ -126,3 +126,12 @@ def test_hip_string_larger_than_batch_is_refused(native):
     r, out, m = run_vkmr(native, "hip:0", b"a\n" + b"b" * 10000 + b"\nc\n", {"VKMR_BATCH_BYTES": "4096"})
     assert b"does not fit an empty batch" in r.stderr
     assert m and int(m["items"]) == 1   # the loop stops at the refused string, like the reference (Vkmr.cpp:44-47)
+
+
+@pytest.mark.gpu
+def test_hip_slice_allocation_failure_is_reported_not_fatal(native):
+    """A slice larger than HBM cannot be allocated: Add() refuses, nothing is printed, exit code 0
+    (reference: allocation failure => Add returns false => loop ends, src/vkmr/Vkmr.cpp:44-52)."""
+    r, out, m = run_vkmr(native, "hip:0", b"a\nb\n", {"VKMR_SLICE_LOG2": "36"})
+    assert r.returncode == 0 and m is None
+    assert b"Failed to allocate slice" in r.stderr

@@ -22,7 +22,7 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_MAX_INFLIGHT")) c.max_inflight = (size_t)atol(e);
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
     if (c.slice_log2 < 1) c.slice_log2 = 1;
-    if (c.slice_log2 > 31) c.slice_log2 = 31;
+    if (c.slice_log2 > 40) c.slice_log2 = 40;   // beyond HBM: the allocation fails and Add() reports it
     if (c.batch_bytes < 4096) c.batch_bytes = 4096;
     if (c.max_inflight < 1) c.max_inflight = 1;
     return c;
@@ -148,11 +148,15 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
     m_reductions->Update();
     if (m_mappings->InFlight()) Account(m_mappings->Update());
 
+    // A failed allocation refuses this string but keeps what was added: the caller stops
+    // reading and Root() still covers the earlier strings (reference: Add returns false,
+    // the partial root is printed, src/vkmr/Vkmr.cpp:44-55, SHA-256vk.cpp:396-399).
     if (!m_slices.Current()) {
-        if (!StartSliceAndBatch()) return (m_ok = false);
+        if (!StartSliceAndBatch()) return false;
     } else if (m_slices.Current().Available() == 0) {
         // the slice is fully reserved: send off what is batched and open the next slice
-        if (!MapCurrent() || !StartSliceAndBatch()) return (m_ok = false);
+        if (!MapCurrent()) return (m_ok = false);
+        if (!StartSliceAndBatch()) return false;
     }
     if (!m_batch.Push(bytes, size)) {
         // batch full: map it and continue in a fresh one on the same device
@@ -180,9 +184,10 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
         m_reductions->Update();
         if (m_mappings->InFlight()) Account(m_mappings->Update());
         if (!m_slices.Current()) {
-            if (!StartSliceAndBatch()) return (m_ok = false);
+            if (!StartSliceAndBatch()) return false;
         } else if (m_slices.Current().Available() == 0) {
-            if (!MapCurrent() || !StartSliceAndBatch()) return (m_ok = false);
+            if (!MapCurrent()) return (m_ok = false);
+            if (!StartSliceAndBatch()) return false;
         }
         Slice& slice = m_slices.Current();
         const PackResult r = m_batch.PushLines(buf + pos, len - pos, final, slice.Available());
