@@ -148,6 +148,17 @@ def test_reduce_to_capacity_height(gpu, oracle, variant):
         assert (got == oracle.reduce_height(leaves, h)).all(), (variant, n, h)
 
 
+def test_reduce_height_zero_returns_the_node(gpu):
+    """height 0 is only valid for one node and returns it unchanged (what the reference's Vulkan path
+    does for a single leaf, Reductions.cpp:471-472; the front end never asks for it: SURVEY.md 8a Q1)."""
+    import vk_merkle_roots_amd as vk
+    leaf = np.arange(8, dtype=np.uint32)[None, :] + 7
+    assert (gpu.reduce_digests(leaf, height=0) == leaf[0]).all()
+    assert (gpu.reduce_digests(leaf, height=0, levels_variant=True) == leaf[0]).all()
+    with pytest.raises(vk.VkmrError):
+        gpu.reduce_digests(np.zeros((2, 8), np.uint32), height=0)
+
+
 def test_reduce_does_not_modify_the_slice(gpu):
     rng = np.random.default_rng(3)
     leaves = rng.integers(0, 2**32, size=(10000, 8), dtype=np.uint32)
