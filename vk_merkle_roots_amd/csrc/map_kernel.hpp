@@ -1,0 +1,296 @@
+// map_kernel.hpp -- the MAP kernel: SHA-256d of every packed string (gfx950).
+// Replaces the reference's shader entry `_SHA_256_N_` (src/shaders/SHA-256.comp:177-304).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vkmr_hip.h"
+#include "sha256d_device.hpp"
+
+using vkmr_dev::Node;
+
+// ============================================================================
+// MAP
+// ============================================================================
+//
+// One workgroup maps one TILE of up to 2048 consecutive strings:
+//   1. metadata -> LDS, block count per string, counting sort of the tile by block
+//      count (longest first) so that the 64 lanes of a wavefront run the same number
+//      of compressions -- one lane per string without the sort runs every wavefront
+//      at the pace of its longest string;
+//   2. wavefronts pull groups of 64 sorted strings and hash them block by block:
+//      16 message words per lane, byte swap, 0x80 / zero / bit-length padding by masks
+//      (no branches), 64 unrolled rounds with the schedule ring in VGPRs.
+// How the 16 words reach the lane is the template parameter MODE (all three are kept,
+// parity-tested and timed against each other: profiles/r01_map_fetch_modes.txt,
+// profiles/r01_map_fetch_vs_tile.txt):
+//   MODE 0  the tile's packed bytes are copied to LDS with coalesced 16-byte HBM loads and
+//           lanes read LDS (the layout the north star describes).  Shipped for short
+//           strings: every byte crosses the HBM interface exactly once.
+//   MODE 2  four 16-byte loads per lane straight from HBM/L2 (strings are 4-byte aligned;
+//           gfx950 takes dword-aligned dwordx4).  No LDS, 7 waves/SIMD.  Shipped for long
+//           strings (>= 128 B on average); for short ones it is 1-2 % faster than MODE 0 but
+//           a 128-byte line shared by strings of different block counts is used at different
+//           times and re-fetched once it has left L2 (1.6x the algorithmic bytes at L2/fabric).
+//   MODE 1  per-wavefront gather: 16 lanes read one string's 64 contiguous bytes, four
+//           strings per load, transposed through LDS rows.  Kept as the measured alternative.
+// The kernel is bound by VALU issue, not by bytes: the three modes are within 5 % of
+// each other.
+// Digest i lands in out[i] whatever the processing order.
+
+#define VKMR_MAP_STAGE_PAD 32
+#define VKMR_MAP_GATHER_STRIDE 20   // words per string row in the gather area: 80 B keeps ds_read_b128 conflict-free
+#define VKMR_MAP_BINS 64
+
+#ifdef VKMR_MAP_STAMPS
+// Diagnostic build only (tools/map_stamps.py): per-phase shader-clock totals of the map
+// kernel, accumulated by lane 0 of every workgroup.  Never compiled into the product.
+__device__ unsigned long long g_map_stamps[32768 * 8];   // 8 words per workgroup, no atomics
+#define VKMR_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define VKMR_STAMP(var)
+#endif
+
+__device__ __forceinline__ uint32_t block_count(uint32_t size) { return (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u; }
+
+// THREADS lanes per workgroup, tiles of at most MAX_TILE strings, STAGE_WORDS words of LDS staging.
+// GATHER selects how a tile that is not staged reads HBM: per wavefront through LDS rows
+// (the long-string kernel) or, in the short-string kernel where that is the rare
+// exception, simply per lane.
+// FULLFAST adds a wave-uniform fast path for blocks in which every string of the group
+// still has 64 bytes (long strings); short-string batches are faster without the test.
+template <int THREADS, int MAX_TILE, int STAGE_WORDS, int MODE, bool FULLFAST = false>
+__global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
+                                                      const vkmr_metadata* __restrict__ meta, uint32_t count,
+                                                      Node* __restrict__ out, uint32_t tile)
+{
+    constexpr int VKMR_MAP_THREADS = THREADS, VKMR_MAP_MAX_TILE = MAX_TILE, VKMR_MAP_STAGE_WORDS = STAGE_WORDS;
+    constexpr bool GATHER = (MODE == 1);   // MODE 0: stage tiles in LDS; 1: per-wavefront gather; 2: per-lane 16-byte loads
+    static_assert(!GATHER || STAGE_WORDS >= (THREADS / 64) * 64 * VKMR_MAP_GATHER_STRIDE, "staging area must hold the gather rows");
+    __shared__ uint4 s_stage4[(VKMR_MAP_STAGE_WORDS + VKMR_MAP_STAGE_PAD) / 4];
+    __shared__ uint2 s_meta[VKMR_MAP_MAX_TILE];
+    __shared__ uint16_t s_order[VKMR_MAP_MAX_TILE];
+    __shared__ uint32_t s_hist[VKMR_MAP_BINS];
+    __shared__ uint32_t s_binstart[VKMR_MAP_BINS];
+    __shared__ unsigned long long s_lo, s_hi;
+    __shared__ uint32_t s_next;
+    uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_stage4);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint64_t tile_base = (uint64_t)blockIdx.x * tile;
+    if (tile_base >= count) return;
+    const uint32_t n_tile = (uint32_t)((count - tile_base < tile) ? count - tile_base : tile);
+
+    VKMR_STAMP(t_begin);
+    // The prologue (sort + staging) is a few hundred instructions; a freshly launched
+    // workgroup is the youngest on its SIMDs and would otherwise be starved by the older
+    // workgroups' hashing, holding its LDS and wave slots idle.  Raise its issue priority
+    // until it starts hashing itself.
+    __builtin_amdgcn_s_setprio(3);
+    if (tid < VKMR_MAP_BINS) s_hist[tid] = 0u;
+    if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; s_next = 0u; }
+    __syncthreads();
+
+    // ---- 1. metadata, keys, extent of the tile's packed bytes -------------------------
+    constexpr int PER = VKMR_MAP_MAX_TILE / VKMR_MAP_THREADS;
+    uint32_t key[PER], rank[PER];
+    uint2 mdv[PER];
+    unsigned long long lo = ~0ull, hi = 0ull;
+    // all metadata loads of this lane are issued before any is used (one HBM round trip)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = tid + k * VKMR_MAP_THREADS;
+        mdv[k] = make_uint2(0u, 0u);
+        if (i < n_tile) mdv[k] = reinterpret_cast<const uint2*>(meta)[tile_base + i];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = tid + k * VKMR_MAP_THREADS;
+        key[k] = 0u; rank[k] = 0u;
+        if (i < n_tile) {
+            const uint2 md = mdv[k];
+            s_meta[i] = md;
+            const uint32_t nb = block_count(md.y);
+            key[k] = nb < VKMR_MAP_BINS ? nb : (VKMR_MAP_BINS - 1u);
+            rank[k] = atomicAdd(&s_hist[key[k]], 1u);
+            const unsigned long long b = md.x, e = b + (((unsigned long long)md.y + 3ull) >> 2);
+            lo = b < lo ? b : lo;
+            hi = e > hi ? e : hi;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if (lane == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+
+    // ---- 2. bin starts, longest strings first -------------------------------------------
+    if (tid < VKMR_MAP_BINS) {
+        uint32_t acc = 0u;
+        for (uint32_t j = tid + 1u; j < VKMR_MAP_BINS; ++j) acc += s_hist[j];
+        s_binstart[tid] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = tid + k * VKMR_MAP_THREADS;
+        if (i < n_tile) s_order[s_binstart[key[k]] + rank[k]] = (uint16_t)i;
+    }
+
+    VKMR_STAMP(t_sorted);
+    // ---- 3. stage the tile's packed words (coalesced) -------------------------------------
+    const unsigned long long t_lo = s_lo, t_hi = s_hi;
+    const unsigned long long a0 = t_lo & ~3ull;                 // 16-byte aligned start
+    const bool staged = (MODE == 0) && (t_hi >= t_lo) && (t_hi - a0 <= VKMR_MAP_STAGE_WORDS) && (t_hi <= data_words) &&
+                        ((reinterpret_cast<uintptr_t>(data) & 15u) == 0u);
+    const uint32_t span = staged ? (uint32_t)(t_hi - a0) : 0u;  // words staged
+    if (staged) {
+        // every lane issues all of its 16-byte loads, then all of its LDS stores
+        const uint4* src4 = reinterpret_cast<const uint4*>(data + a0);
+        constexpr int NV = (VKMR_MAP_STAGE_WORDS / 4 + VKMR_MAP_THREADS - 1) / VKMR_MAP_THREADS;
+        uint4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const uint32_t w = (tid + q * VKMR_MAP_THREADS) * 4u;
+            v[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (w < span) {
+                if (a0 + w + 4u <= data_words) {
+                    v[q] = src4[w >> 2];
+                } else {   // last, partial vector of the buffer
+                    v[q].x = data[a0 + w];
+                    v[q].y = (a0 + w + 1u < data_words) ? data[a0 + w + 1u] : 0u;
+                    v[q].z = (a0 + w + 2u < data_words) ? data[a0 + w + 2u] : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const uint32_t w = (tid + q * VKMR_MAP_THREADS) * 4u;
+            if (w < span) s_stage4[w >> 2] = v[q];
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    VKMR_STAMP(t_staged);
+
+    // ---- 4. hash groups of 64 sorted strings ---------------------------------------------
+    const uint32_t ngroups = (n_tile + 63u) >> 6;
+    for (;;) {
+        uint32_t g = 0u;
+        if (lane == 0) g = atomicAdd(&s_next, 1u);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
+        const uint32_t pos = g * 64u + lane;
+        const bool has = pos < n_tile;
+        const uint32_t id = has ? s_order[pos] : 0u;
+        const uint2 md = s_meta[id];
+        const uint32_t start = md.x, size = has ? md.y : 0u;
+        const uint32_t nb = has ? block_count(size) : 0u;
+
+        uint32_t H[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) H[i] = vkmr_dev::IV256[i];
+
+        // Gather path (tile not staged): the wavefront fetches its 64 strings' blocks
+        // cooperatively -- 16 lanes read the 64 contiguous bytes of one string's block, 4
+        // strings per load instruction -- through this wavefront's private LDS rows, so
+        // HBM/L2 see 64-byte segments instead of 64 scattered dwords per instruction.
+        const uint32_t sub = lane >> 4, wi = lane & 15u;
+        uint32_t* wl = s_stage + (tid >> 6) * (64u * VKMR_MAP_GATHER_STRIDE);
+        uint32_t gstart[GATHER ? 16 : 1];
+        if (GATHER && !staged) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gstart[GATHER ? j : 0] = __shfl(start, 4 * j + (int)sub);
+        }
+
+        for (uint32_t b = 0; __any(b < nb); ++b) {
+            uint32_t w[16];
+            // raw words of this block (garbage beyond the string is masked below)
+            if (staged) {
+                uint32_t base = (uint32_t)(start - a0) + (b << 4);
+                base = base < span ? base : span;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = s_stage[base + i];
+            } else if (!GATHER) {
+                // per lane, straight from HBM/L2: four 16-byte loads (strings are only 4-byte
+                // aligned; gfx950 takes dword-aligned dwordx4), scalar loads at the buffer's end
+                const uint64_t gbase = (uint64_t)start + ((uint64_t)b << 4);
+                if (gbase + 16u <= data_words) {
+                    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4_u* src = reinterpret_cast<const u32x4_u*>(data + gbase);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32x4_u v = src[q];
+                        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint64_t idx = gbase + i;
+                        w[i] = (idx < data_words) ? data[idx] : 0u;
+                    }
+                }
+            } else {
+                uint32_t g[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t idx = (uint64_t)gstart[GATHER ? j : 0] + ((uint64_t)b << 4) + wi;
+                    g[j] = (idx < data_words) ? data[idx] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) wl[(4 * j + sub) * VKMR_MAP_GATHER_STRIDE + wi] = g[j];
+                const uint4* row = reinterpret_cast<const uint4*>(wl + lane * VKMR_MAP_GATHER_STRIDE);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 v = row[q];
+                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                }
+            }
+            // valid bytes of the string inside this block: 0..64
+            const uint64_t boff = (uint64_t)b << 6;
+            const uint32_t r = (boff >= size) ? 0u : ((size - boff >= 64u) ? 64u : (uint32_t)(size - boff));
+            if (FULLFAST && __all(r == 64u || b >= nb)) {
+                // every string of the group still has 64 bytes here: plain byte swap
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(w[i]);
+            } else {
+                const bool term_here = (boff <= size) && (size - boff < 64u);   // the 0x80 byte falls in this block
+                const uint32_t bw = term_here ? (r >> 2) : 16u;                 // word holding the terminator
+                const uint32_t kb = (r & 3u) << 3;
+                const uint32_t keep = kb ? (0xFFFFFFFFu << (32u - kb)) : 0u;
+                const uint32_t padbit = 0x80000000u >> kb;
+                const uint32_t full = r >> 2;                                   // whole data words
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t v = __builtin_bswap32(w[i]);
+                    const uint32_t bnd = (v & keep) | padbit;
+                    w[i] = ((uint32_t)i < full) ? v : (((uint32_t)i == bw) ? bnd : 0u);
+                }
+            }
+            if (b + 1u == nb) {   // last block carries the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
+                w[14] = size >> 29;
+                w[15] = size << 3;
+            }
+            if (b < nb) vkmr_dev::compress(H, w);
+        }
+        if (has) {
+            uint32_t o[8];
+            vkmr_dev::hash_digest(H, o);
+            vkmr_dev::store_node(out + tile_base + id, o);
+        }
+    }
+#ifdef VKMR_MAP_STAMPS
+    {
+        unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 32768u) {   // wavefront 0 of each workgroup: its own phase boundaries
+            unsigned long long* o = g_map_stamps + (size_t)blockIdx.x * 8;
+            o[0] = t_begin; o[1] = t_sorted; o[2] = t_staged; o[3] = t_end; o[4] = rt;
+        }
+    }
+#endif
+}
+

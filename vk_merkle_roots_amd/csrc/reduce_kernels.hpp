@@ -1,0 +1,220 @@
+// reduce_kernels.hpp -- the REDUCE kernels: pairwise SHA-256d tree over a slice of digests (gfx950).
+// Replace the reference's shader entries `_SHA_256_2_BE_` with and without `_VKMR_BY_SUBGROUP_`
+// (src/shaders/SHA-256.comp:308-434).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sha256d_device.hpp"
+
+using vkmr_dev::Node;
+
+// ============================================================================
+// REDUCE
+// ============================================================================
+
+#define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel
+#define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass
+
+__device__ __forceinline__ uint64_t level_count(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
+
+// Each wave walks 2^m chunks of 128 consecutive nodes.  A chunk gives 64 level-1
+// nodes (one per lane).  Two such results of equal level merge into 64 nodes of
+// the next level: lanes 0..31 hash pairs of the earlier (pending) result, lanes
+// 32..63 pairs of the later one, so every step keeps all 64 lanes busy.  Pending
+// results wait in this wave's LDS region (64 nodes per level); the later half is
+// fetched from its lanes' registers with __shfl (ds_bpermute_b32).  After the last
+// chunk the wave holds 64 nodes of level m+1 and writes them out coalesced.
+// Pairing rule at every level: a node without a right sibling is paired with itself
+// (src/shaders/SHA-256.comp:337, :363).
+// Several equal-capacity slices can be reduced by one launch: blockIdx.y picks the
+// slice (input `in_stride` nodes apart, output `out_stride` apart); the last slice
+// may hold fewer nodes (`n_last`) than the others (`n_full`).
+struct SliceGeom { uint64_t n_full, n_last, in_stride, out_stride; uint32_t nslices; };
+
+__device__ __forceinline__ uint64_t slice_count(const SliceGeom& g) { return (blockIdx.y + 1u == g.nslices) ? g.n_last : g.n_full; }
+
+__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const Node* __restrict__ in0, SliceGeom geom,
+                                                                           Node* __restrict__ out0, uint32_t m)
+{
+    const uint64_t n_in = slice_count(geom);
+    const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
+    Node* __restrict__ out = out0 + blockIdx.y * geom.out_stride;
+    __shared__ uint4 pend_store[VKMR_PASS_WAVES * VKMR_PASS_MAXM * 64 * 2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t gwave = (uint64_t)blockIdx.x * VKMR_PASS_WAVES + wave;
+    const uint64_t base0 = gwave * (128ull << m);
+    if (base0 >= n_in) return;   // wave-uniform; no workgroup barrier is used below
+    Node* pend = reinterpret_cast<Node*>(pend_store) + wave * (VKMR_PASS_MAXM * 64);
+
+    uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t chunks = 1u << m;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        uint32_t cc = c;
+        uint32_t k = 0;   // this step turns level-k nodes into level-(k+1) nodes
+        for (;;) {
+            // first input node covered by this step, and this lane's output index
+            const uint64_t first = base0 + 128ull * ((uint64_t)c + 1ull - (1ull << k));
+            if (first < n_in) {   // wave-uniform: otherwise nothing below is a real node
+                const uint64_t j = (first >> (k + 1)) + lane;
+                const uint64_t ck = level_count(n_in, k);
+                uint32_t l[8], r[8];
+                if (k == 0) {
+                    if (2 * j < ck) {
+                        const Node a = vkmr_dev::load_node(in + 2 * j);
+                        const Node b = (2 * j + 1 < ck) ? vkmr_dev::load_node(in + 2 * j + 1) : a;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { l[i] = a.w[i]; r[i] = b.w[i]; }
+                    }
+                } else {
+                    const uint32_t src = (2u * lane) & 63u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        l[i] = __shfl(X[i], src);
+                        r[i] = __shfl(X[i], src + 1u);
+                    }
+                    if (lane < 32u) {
+                        const Node a = pend[(k - 1) * 64 + 2 * lane];
+                        const Node b = pend[(k - 1) * 64 + 2 * lane + 1];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { l[i] = a.w[i]; r[i] = b.w[i]; }
+                    }
+                    if (2 * j + 1 >= ck) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) r[i] = l[i];
+                    }
+                }
+                if (2 * j < ck) vkmr_dev::hash_pair(l, r, X);
+            }
+            ++k;
+            if (!(cc & 1u)) break;
+            cc >>= 1;
+        }
+        if (c + 1u != chunks) {
+            Node t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t.w[i] = X[i];
+            pend[(k - 1) * 64 + lane] = t;
+        }
+    }
+    const uint64_t jo = (base0 >> (m + 1)) + lane;
+    if (jo < level_count(n_in, m + 1)) vkmr_dev::store_node(out + jo, X);
+}
+
+// Top of the tree: up to VKMR_TAIL_MAX nodes, exactly `levels` levels, one
+// workgroup.  Level 1 comes from a coalesced pair load; the next six levels stay
+// inside each 64-lane wavefront with __shfl_down, exactly the shape of the
+// reference's subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377); up to
+// sixteen wave results then meet in LDS and one wave finishes with __shfl_down.
+// Any levels left once a single node remains hash that node with itself
+// ("keep iterating", README.md:94).
+__device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0, uint32_t lane, uint64_t n_in,
+                                                 uint32_t& done, uint32_t levels, uint32_t steps)
+{
+    for (uint32_t t = 0; t < steps && done < levels; ++t) {
+        const uint64_t cnt = level_count(n_in, done);   // nodes alive at the current level
+        const uint64_t me = idx0 >> t;                   // this lane's node index at that level
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = __shfl_down(X[i], 1u << t);
+        if (me + 1 >= cnt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = X[i];
+        }
+        if ((lane & ((2u << t) - 1u)) == 0u && me < cnt) {
+            uint32_t o[8];
+            vkmr_dev::hash_pair(X, r, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) X[i] = o[i];
+        }
+        ++done;
+    }
+}
+
+__global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                           Node* __restrict__ root0)
+{
+    const uint32_t n_in = (uint32_t)slice_count(geom);
+    const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
+    Node* __restrict__ root = root0 + blockIdx.y * geom.out_stride;
+    __shared__ Node wave_out[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t done = 0;
+    if (levels == 0) {   // n_in == 1: the root is the node itself
+        if (tid == 0) *root = in[0];
+        return;
+    }
+    if (2 * tid < n_in) {
+        const Node a = vkmr_dev::load_node(in + 2 * tid);
+        const Node b = (2 * tid + 1 < n_in) ? vkmr_dev::load_node(in + 2 * tid + 1) : a;
+        vkmr_dev::hash_pair(a.w, b.w, X);
+    }
+    done = 1;
+    shuffle_collapse(X, tid, lane, n_in, done, levels, 6);
+    if (done < levels) {   // uniform across the workgroup
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wave_out[wave].w[i] = X[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (lane < 16u && lane < (blockDim.x >> 6)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) X[i] = wave_out[lane].w[i];
+            }
+            shuffle_collapse(X, lane, lane, n_in, done, levels, 4);
+            while (done < levels) {   // a single node left: pair it with itself
+                uint32_t o[8];
+                vkmr_dev::hash_pair(X, X, o);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) X[i] = o[i];
+                ++done;
+            }
+        }
+    }
+    if (tid == 0) vkmr_dev::store_node(root, X);
+}
+
+// Middle of the tree, where there are too few nodes to keep every SIMD busy: one
+// wavefront per workgroup (so the wavefronts spread over all CUs) collapses 128
+// nodes through `levels` (1..7) levels -- a coalesced pair load, then __shfl_down
+// steps as in the reference's subgroup shader.  Lane utilisation is poor by
+// construction here but these passes are latency-bound: what counts
+// is the ~9 us one wavefront needs per level, not the idle lanes.
+__global__ __launch_bounds__(64) void reduce_collapse_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                             Node* __restrict__ out0)
+{
+    const uint64_t n_in = slice_count(geom);
+    const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
+    Node* __restrict__ out = out0 + blockIdx.y * geom.out_stride;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;   // level-1 node of this lane
+    uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (2 * j < n_in) {
+        const Node a = vkmr_dev::load_node(in + 2 * j);
+        const Node b = (2 * j + 1 < n_in) ? vkmr_dev::load_node(in + 2 * j + 1) : a;
+        vkmr_dev::hash_pair(a.w, b.w, X);
+    }
+    uint32_t done = 1;
+    shuffle_collapse(X, j, lane, n_in, done, levels, 6);
+    const uint64_t jo = j >> (levels - 1u);
+    if ((lane & ((1u << (levels - 1u)) - 1u)) == 0u && jo < level_count(n_in, levels)) vkmr_dev::store_node(out + jo, X);
+}
+
+// One level, one lane per pair (reference's BasicReduction shader, SHA-256.comp:393-434,
+// with `>=` bounds and self-pairing instead of the duplicate-last buffer copy,
+// src/vkmr/Reductions.cpp:299-342).
+__global__ __launch_bounds__(256) void reduce_level_kernel(const Node* __restrict__ in, uint64_t n_in, Node* __restrict__ out)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * p >= n_in) return;
+    const Node a = vkmr_dev::load_node(in + 2 * p);
+    const Node b = (2 * p + 1 < n_in) ? vkmr_dev::load_node(in + 2 * p + 1) : a;
+    uint32_t o[8];
+    vkmr_dev::hash_pair(a.w, b.w, o);
+    vkmr_dev::store_node(out + p, o);
+}
+
