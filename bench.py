@@ -158,15 +158,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     tdev = None
+    collective = None
     if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+        collective = a.dist_backend
         if a.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            tdev = torch.device("cuda", local_rank)
-            dist.init_process_group(backend="nccl", device_id=tdev, rank=rank, world_size=world)
+            try:
+                torch.cuda.set_device(local_rank)
+                tdev = torch.device("cuda", local_rank)
+                dist.init_process_group(backend="nccl", device_id=tdev, rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=tdev)
+                dist.all_reduce(probe)            # first RCCL collective: fail here, not inside the timed region
+                torch.cuda.synchronize()
+            except Exception as e:                # RCCL unusable on this node: the 32-byte gather goes over gloo, and says so
+                sys.stderr.write(f"[bench] nccl/RCCL init failed on rank {rank}: {e!r}; falling back to gloo for the root gather\n")
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                tdev = None
+                collective = "gloo (RCCL init failed)"
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
             local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -316,7 +333,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"rndm {a.seed}+rank 2^{a.leaves_log2} {a.maxlen} per GPU (BASELINE configs[2])",
                        "leaves_per_gpu": n, "slices_per_gpu": nslices, "slice_capacity": cap, "map_launches_per_step": nbatches,
-                       "input_bytes_per_gpu": int(input_bytes), "parallelism": f"slices sharded over {world} GPU(s)",
+                       "input_bytes_per_gpu": int(input_bytes), "parallelism": f"slices sharded over {world} GPU(s)", "collective": (collective if dist is not None else None),
                        "kernels": dev.lib.vkmr_hip_kernel_info().decode(), "reduce_variant": "levels" if a.levels_variant else "wave"},
             "root": digest_hex(final),
             "merkle_root_wall_ms": ms_per_step,
