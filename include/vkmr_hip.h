@@ -116,7 +116,9 @@ VKMR_API vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_e
  *   out_dev     count digest cells (a sub-slice, src/vkmr/Slices.h:145-187)
  * Deliberate differences from the shader: bounds test is `>=`
  * (Q4), tail bytes of the last word are masked to `size` (Q3), the 64-bit length
- * uses size>>29 for the high word.  size == 0 hashes the empty string.
+ * uses size>>29 for the high word.  size == 0 hashes the empty string.  A string whose
+ * metadata runs past data_words is cut at the end of the buffer (bounded work for
+ * corrupt metadata; the shader would read out of bounds).
  */
 VKMR_API vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s,
                                         const uint32_t* data_dev, uint64_t data_words,

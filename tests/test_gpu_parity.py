@@ -93,16 +93,19 @@ def test_map_metadata_in_any_order(gpu, oracle):
 
 
 def test_map_out_of_range_metadata_does_not_fault(gpu, oracle):
-    """A start/size pointing past data_words must not read out of bounds: missing words hash as zeros."""
+    """A start/size pointing past data_words must not read out of bounds nor spin: the string is cut
+    at the end of the buffer (include/vkmr_hip.h, vkmr_hip_map_async)."""
     import vk_merkle_roots_amd as vk
     b = vk.rndm_packed(32, 1000, 127)
     meta = b.meta.copy()
-    meta[10] = (b.words - 1, 64)            # runs 15 words past the end
-    meta[20] = (b.words + 1000, 5)          # entirely outside
+    meta[10] = (b.words - 1, 64)            # runs 15 words past the end -> 4 bytes left
+    meta[20] = (b.words + 1000, 5)          # entirely outside -> empty string
+    meta[30] = (b.words - 2, 0xFFFFFFF0)    # 4 GiB claimed, 8 bytes left
     meta[999] = (b.words - 2, 200)
     got = gpu.leaf_digests(vk.PackedBatch(b.data, meta, b.words, 0))
-    padded = np.concatenate([b.data, np.zeros(2000, dtype=np.uint32)])
-    want = oracle.leaves_packed(padded, meta)
+    cut = meta.copy()
+    cut[10, 1], cut[20], cut[30, 1], cut[999, 1] = 4, (0, 0), 8, 8
+    want = oracle.leaves_packed(b.data, cut)
     assert (got == want).all()
 
 

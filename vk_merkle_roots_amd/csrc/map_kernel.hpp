@@ -108,7 +108,11 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
         const uint32_t i = tid + k * VKMR_MAP_THREADS;
         key[k] = 0u; rank[k] = 0u;
         if (i < n_tile) {
-            const uint2 md = mdv[k];
+            uint2 md = mdv[k];
+            // a string that runs past the end of the data buffer is cut at the buffer: corrupt
+            // metadata must not turn into millions of zero-filled blocks on one lane
+            const unsigned long long avail = (md.x < data_words) ? (data_words - md.x) * 4ull : 0ull;
+            md.y = (md.y > avail) ? (uint32_t)avail : md.y;
             s_meta[i] = md;
             const uint32_t nb = block_count(md.y);
             key[k] = nb < VKMR_MAP_BINS ? nb : (VKMR_MAP_BINS - 1u);
