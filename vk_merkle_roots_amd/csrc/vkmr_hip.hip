@@ -487,7 +487,7 @@ vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_dige
     if (!digests_dev || !roots_dev || nslices == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad argument");
     if (count_last == 0 || count_last > capacity || nslices > 65535u)
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad slice geometry");
-    if (!height_ok(capacity, height) || (nslices == 1 && !height_ok(count_last, height)))
+    if (!height_ok(nslices == 1 ? count_last : capacity, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: height does not reduce a slice to one node");
     if (capacity > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
     VKMR_TRY(hipSetDevice(dev));
