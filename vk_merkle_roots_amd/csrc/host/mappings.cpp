@@ -31,7 +31,11 @@ public:
         m.dev = sub.Device();
         m.begin = Event(m.dev);
         m.done = Event(m.dev);
-        if (!m.begin || !m.done) return VKMR_ERR_HIP;
+        if (!m.begin || !m.done) {
+            if (m.begin) m_spare.emplace_back(m.dev, m.begin);
+            if (m.done) m_spare.emplace_back(m.dev, m.done);
+            return VKMR_ERR_HIP;
+        }
         HipResult r = vkmr_hip_event_record(m.dev, m.begin, stream);
         if (r == VKMR_OK)
             r = vkmr_hip_memcpy_h2d_async(m.dev, stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
@@ -44,6 +48,8 @@ public:
         if (r == VKMR_OK) r = vkmr_hip_event_record(m.dev, m.done, stream);
         if (r != VKMR_OK) {
             std::cerr << "Failed to dispatch a mapping: " << vkmr_hip_last_error() << std::endl;
+            m_spare.emplace_back(m.dev, m.begin);   // keep the events for the next mapping
+            m_spare.emplace_back(m.dev, m.done);
             return r;
         }
         m.batch = std::move(batch);
