@@ -135,3 +135,27 @@ def test_hip_slice_allocation_failure_is_reported_not_fatal(native):
     r, out, m = run_vkmr(native, "hip:0", b"a\nb\n", {"VKMR_SLICE_LOG2": "36"})
     assert r.returncode == 0 and m is None
     assert b"Failed to allocate slice" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"VKMR_HIP_VIRTUAL_DEVICES": "2", "VKMR_SLICE_LOG2": "12", "VKMR_BATCH_BYTES": "50000"},
+    {"VKMR_HIP_VIRTUAL_DEVICES": "4", "VKMR_SLICE_LOG2": "16", "VKMR_BATCH_MB": "1", "VKMR_MAX_INFLIGHT": "3"},
+    {"VKMR_HIP_VIRTUAL_DEVICES": "3", "VKMR_SLICE_LOG2": "10", "VKMR_BATCH_BYTES": "8192"},
+])
+def test_hip_all_shards_slices_over_devices(native, golden, env):
+    """"hip:all": slices round-robin over every device, per-device streams and batch pools, roots combined in
+    slice order.  VKMR_HIP_VIRTUAL_DEVICES enumerates the one GPU several times so the path runs here."""
+    for name in ("G2_rndm_1712489279_1024_127", "G3_rndm_42_1048576_127", "G6_rndm_7_1000_300", "L7_three"):
+        s = golden["streams"][name]
+        r, out, m = run_vkmr(native, "hip:all", golden_stream(native, s), env)
+        assert r.returncode == 0 and out[0] == "Initializing for: hip:all", (name, r.stderr[-400:])
+        assert m and (m["name"], int(m["items"]), m["root"]) == ("hip:all", s["items"], s["root"]), (name, env)
+
+
+@pytest.mark.gpu
+def test_device_listing_with_several_devices(native):
+    r, out, m = run_vkmr(native, None, b"a\n", {"VKMR_HIP_VIRTUAL_DEVICES": "2"})
+    assert r.returncode == 1
+    for want in (b"* CPU", b"* hip:0", b"* hip:1", b"* hip:all"):
+        assert want in r.stderr

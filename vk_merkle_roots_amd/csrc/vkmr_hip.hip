@@ -53,6 +53,25 @@ static vkmr_status from_hip(hipError_t e, const char* what)
         if (st__ != VKMR_OK) return st__;                \
     } while (0)
 
+// VKMR_HIP_VIRTUAL_DEVICES=k (test facility): every physical GPU is enumerated k times, so that the
+// multi-device host paths ("hip:all": slices round-robin over devices, per-device streams and pools)
+// can be exercised on a single-GPU machine.  Device index d maps to physical GPU d % real.
+static int g_real_devices = -1;
+static int virtual_factor()
+{
+    static const int k = [] { const char* e = getenv("VKMR_HIP_VIRTUAL_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    return k;
+}
+static inline int phys(int dev)
+{
+    if (g_real_devices < 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        g_real_devices = n;
+    }
+    return (g_real_devices > 0 && dev >= 0) ? dev % g_real_devices : dev;
+}
+
 static inline hipStream_t S(vkmr_stream s) { return reinterpret_cast<hipStream_t>(s); }
 static inline hipEvent_t E(vkmr_event e) { return reinterpret_cast<hipEvent_t>(e); }
 
@@ -83,7 +102,8 @@ vkmr_status vkmr_hip_device_count(int* count)
         fail(VKMR_OK, "hipGetDeviceCount", e);
         return VKMR_OK;
     }
-    *count = n;
+    g_real_devices = n;
+    *count = n * virtual_factor();
     return VKMR_OK;
 }
 
@@ -91,7 +111,7 @@ vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen)
 {
     if (!buf || buflen == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_name: null buffer");
     hipDeviceProp_t p;
-    VKMR_TRY(hipGetDeviceProperties(&p, dev));
+    VKMR_TRY(hipGetDeviceProperties(&p, phys(dev)));
     // some ROCm installs leave the marketing name empty: fall back to the ISA name
     snprintf(buf, buflen, "%s", p.name[0] ? p.name : p.gcnArchName);
     return VKMR_OK;
@@ -100,7 +120,7 @@ vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen)
 vkmr_status vkmr_hip_device_mem_info(int dev, size_t* free_bytes, size_t* total_bytes)
 {
     if (!free_bytes || !total_bytes) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_mem_info: null out pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipMemGetInfo(free_bytes, total_bytes));
     return VKMR_OK;
 }
@@ -108,7 +128,7 @@ vkmr_status vkmr_hip_device_mem_info(int dev, size_t* free_bytes, size_t* total_
 vkmr_status vkmr_hip_device_geometry(int dev, int* compute_units, int* wavefront)
 {
     hipDeviceProp_t p;
-    VKMR_TRY(hipGetDeviceProperties(&p, dev));
+    VKMR_TRY(hipGetDeviceProperties(&p, phys(dev)));
     if (compute_units) *compute_units = p.multiProcessorCount;
     if (wavefront) *wavefront = p.warpSize;
     return VKMR_OK;
@@ -134,7 +154,7 @@ vkmr_status vkmr_hip_host_free(void* p)
 vkmr_status vkmr_hip_device_alloc(int dev, size_t bytes, void** out)
 {
     if (!out || bytes == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_alloc: bad argument");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     void* p = nullptr;
     VKMR_TRY(hipMalloc(&p, bytes));
     *out = p;
@@ -144,7 +164,7 @@ vkmr_status vkmr_hip_device_alloc(int dev, size_t bytes, void** out)
 vkmr_status vkmr_hip_device_free(int dev, void* p)
 {
     if (!p) return VKMR_OK;
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipFree(p));
     return VKMR_OK;
 }
@@ -152,7 +172,7 @@ vkmr_status vkmr_hip_device_free(int dev, void* p)
 vkmr_status vkmr_hip_memset_async(int dev, vkmr_stream s, void* dst, int value, size_t bytes)
 {
     if (!dst) return fail(VKMR_ERR_INVALID, "vkmr_hip_memset_async: null pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipMemsetAsync(dst, value, bytes, S(s)));
     return VKMR_OK;
 }
@@ -160,7 +180,7 @@ vkmr_status vkmr_hip_memset_async(int dev, vkmr_stream s, void* dst, int value, 
 vkmr_status vkmr_hip_memcpy_h2d_async(int dev, vkmr_stream s, void* dst_dev, const void* src_host, size_t bytes)
 {
     if (!dst_dev || !src_host) return fail(VKMR_ERR_INVALID, "vkmr_hip_memcpy_h2d_async: null pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(s)));
     return VKMR_OK;
 }
@@ -168,7 +188,7 @@ vkmr_status vkmr_hip_memcpy_h2d_async(int dev, vkmr_stream s, void* dst_dev, con
 vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (!dst_host || !src_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_memcpy_d2h_async: null pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(s)));
     return VKMR_OK;
 }
@@ -176,7 +196,7 @@ vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst_host, co
 vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
 {
     if (!out) return fail(VKMR_ERR_INVALID, "vkmr_hip_stream_create: null out pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     hipStream_t s;
     VKMR_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *out = reinterpret_cast<vkmr_stream>(s);
@@ -186,14 +206,14 @@ vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
 vkmr_status vkmr_hip_stream_destroy(int dev, vkmr_stream s)
 {
     if (!s) return VKMR_OK;
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipStreamDestroy(S(s)));
     return VKMR_OK;
 }
 
 vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s)
 {
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipStreamSynchronize(S(s)));
     return VKMR_OK;
 }
@@ -201,7 +221,7 @@ vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s)
 vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out)
 {
     if (!out) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_create: null out pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     hipEvent_t e;
     VKMR_TRY(hipEventCreate(&e));
     *out = reinterpret_cast<vkmr_event>(e);
@@ -211,7 +231,7 @@ vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out)
 vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e)
 {
     if (!e) return VKMR_OK;
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipEventDestroy(E(e)));
     return VKMR_OK;
 }
@@ -219,7 +239,7 @@ vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e)
 vkmr_status vkmr_hip_event_record(int dev, vkmr_event e, vkmr_stream s)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_record: null event");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipEventRecord(E(e), S(s)));
     return VKMR_OK;
 }
@@ -227,7 +247,7 @@ vkmr_status vkmr_hip_event_record(int dev, vkmr_event e, vkmr_stream s)
 vkmr_status vkmr_hip_event_query(int dev, vkmr_event e)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_query: null event");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     hipError_t r = hipEventQuery(E(e));
     if (r == hipErrorNotReady) {
         (void)hipGetLastError();
@@ -239,7 +259,7 @@ vkmr_status vkmr_hip_event_query(int dev, vkmr_event e)
 vkmr_status vkmr_hip_event_wait(int dev, vkmr_event e)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_wait: null event");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipEventSynchronize(E(e)));
     return VKMR_OK;
 }
@@ -247,7 +267,7 @@ vkmr_status vkmr_hip_event_wait(int dev, vkmr_event e)
 vkmr_status vkmr_hip_stream_wait_event(int dev, vkmr_stream s, vkmr_event e)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_stream_wait_event: null event");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipStreamWaitEvent(S(s), E(e), 0));
     return VKMR_OK;
 }
@@ -255,7 +275,7 @@ vkmr_status vkmr_hip_stream_wait_event(int dev, vkmr_stream s, vkmr_event e)
 vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end, float* ms)
 {
     if (!begin || !end || !ms) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_elapsed_ms: null argument");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     VKMR_TRY(hipEventElapsedTime(ms, E(begin), E(end)));
     return VKMR_OK;
 }
@@ -268,7 +288,7 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     if (count == 0) return VKMR_OK;
     if (!meta_dev || !out_dev || (!data_dev && data_words != 0))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     // VKMR_MAP_VARIANT picks an alternative fetch mode / geometry for A/B timing; 0 = shipped.
     static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
@@ -436,7 +456,7 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* dig
     if (!height_ok(count, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: height does not reduce count to one node");
     if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), 1, count, count, height,
                          reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
 }
@@ -450,7 +470,7 @@ vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s, const vkmr_digest* dige
     if (!height_ok(count, height)) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: height does not reduce count to one node");
     if (index >= count) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: index out of range");
     if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null scratch");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     const Node* leaves = reinterpret_cast<const Node*>(digests_dev);
     Node* sib = reinterpret_cast<Node*>(siblings_dev);
     for (uint32_t l = 0; l < height; ++l) {
@@ -490,7 +510,7 @@ vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_dige
     if (!height_ok(nslices == 1 ? count_last : capacity, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: height does not reduce a slice to one node");
     if (capacity > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), nslices, nslices == 1 ? count_last : capacity,
                          count_last, height, reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(roots_dev));
 }
@@ -507,7 +527,7 @@ vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_dige
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: null pointer");
     if (!height_ok(count, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: height does not reduce count to one node");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     const Node* in = reinterpret_cast<const Node*>(digests_dev);
     Node* bufA = reinterpret_cast<Node*>(scratch_dev);
     Node* bufB = bufA + ceil_shift(count, 1);
@@ -530,7 +550,7 @@ vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_dige
 vkmr_status vkmr_hip_combine(int dev, const vkmr_digest* roots_host, uint32_t n, vkmr_digest* out_host)
 {
     if (!roots_host || !out_host || n == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_combine: bad argument");
-    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipSetDevice(phys(dev)));
     uint32_t height = 1;   // at least one level: CpuSha256D::Root's do-while (SHA-256plus.cpp:515-547)
     while (ceil_shift(n, height) > 1) ++height;
     const size_t scratch = vkmr_hip_reduce_scratch_bytes(n);
