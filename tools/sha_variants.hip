@@ -4,6 +4,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/sha_variants tools/sha_variants.hip && ./tools/sha_variants
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "../vk_merkle_roots_amd/csrc/sha256d_device.hpp"
 
 using namespace vkmr_dev;
@@ -111,9 +112,12 @@ void run(const char* name, const Node* in, Node* out, int blocks, int reps, uint
     if (!check[0]) check[0] = h[0];
 }
 
-int main()
+int main(int argc, char** argv)
 {
-    const int blocks = 256 * 8, reps = 64;   // 8 workgroups of 4 wavefronts per CU
+    // argv[1]: workgroups (4 wavefronts each) per CU -- occupancy sweep: does the chip clock higher with fewer waves?
+    const int bpc = argc > 1 ? atoi(argv[1]) : 8;
+    const int blocks = 256 * bpc, reps = 64 * 8 / bpc;
+    printf("-- %d workgroups of 4 wavefronts per CU (%d waves/SIMD)\n", bpc, bpc);
     Node *in, *out;
     (void)hipMalloc(&in, (size_t)blocks * 256 * 2 * sizeof(Node));
     (void)hipMalloc(&out, (size_t)blocks * 256 * sizeof(Node));
