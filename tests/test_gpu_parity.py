@@ -183,7 +183,7 @@ def test_reduce_slices_batched(gpu, oracle):
     """Several slices, short last one, reduced by one batched call (every slice to capacity height)."""
     rng = np.random.default_rng(6)
     for cap_log2, nslices, last in [(8, 3, 256), (8, 3, 1), (10, 5, 700), (13, 4, 8191), (18, 3, 100000), (19, 2, 524288),
-                                    (7, 9, 5), (15, 1, 20000), (8, 1500, 77), (10, 600, 1024), (9, 3000, 300), (12, 40, 1)]:
+                                    (7, 9, 5), (15, 1, 20000), (8, 1500, 77), (10, 600, 1024), (9, 3000, 300), (12, 40, 1), (1, 70001, 1), (2, 40000, 3)]:
         cap = 1 << cap_log2
         n = (nslices - 1) * cap + last
         leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)

@@ -1,0 +1,22 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, vk_merkle_roots_amd as vk
+from conftest import Oracle
+o = Oracle(); gpu = vk.HipDevice(0)
+rng = np.random.default_rng(int(time.time()))
+t0 = time.time(); cases = 0
+while time.time() - t0 < 90:
+    # random stream -> root via random slicing, both map modes via batched/unbatched engine paths
+    n = int(rng.choice([rng.integers(1, 2000), rng.integers(1, 200000)]))
+    maxlen = int(rng.choice([2, 20, 65, 127, 300, 2000]))
+    seed = int(rng.integers(1, 2**31))
+    b = vk.rndm_packed(seed, n, maxlen)
+    want = o.hex(o.root(o.leaves_packed(b.data, b.meta, threads=16), threads=16))
+    cap = 1 << int(rng.integers(1, 19))
+    bs = int(rng.integers(1, max(2, n)))
+    got1 = vk.merkle_root_packed(gpu, b, slice_capacity=cap, batch_strings=max(bs, n // 50 + 1))
+    got2 = vk.merkle_root_packed_batched(gpu, b, slice_capacity=cap, batch_strings=max(bs, n // 50 + 1))
+    got3 = vk.merkle_root_packed(gpu, b)
+    assert got1 == want and got2 == want and got3 == want, (seed, n, maxlen, cap, bs)
+    cases += 1
+print("soak ok:", cases, "random streams, all roots equal the oracle")

@@ -494,25 +494,46 @@ vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s, const vkmr_digest* dige
     return VKMR_OK;
 }
 
-size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
-{
-    if (nslices == 0) nslices = 1;
-    return (size_t)scratch_cells(capacity, nslices) * nslices * sizeof(vkmr_digest);
-}
-
 vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint32_t nslices,
                                          uint64_t capacity, uint64_t count_last, uint32_t height, void* scratch_dev,
                                          vkmr_digest* roots_dev)
 {
     if (!digests_dev || !roots_dev || nslices == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad argument");
-    if (count_last == 0 || count_last > capacity || nslices > 65535u)
+    if (count_last == 0 || count_last > capacity)
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad slice geometry");
     if (!height_ok(nslices == 1 ? count_last : capacity, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: height does not reduce a slice to one node");
     if (capacity > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
     VKMR_TRY(hipSetDevice(phys(dev)));
-    return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), nslices, nslices == 1 ? count_last : capacity,
-                         count_last, height, reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(roots_dev));
+    // grid.y carries the slice index: at most 32768 slices per launch sequence; longer runs go in
+    // chunks on the same stream (the scratch is reused, the stream serialises them)
+    const uint32_t chunk = 32768u;
+    const Node* digests = reinterpret_cast<const Node*>(digests_dev);
+    Node* roots = reinterpret_cast<Node*>(roots_dev);
+    for (uint32_t first = 0; first < nslices; first += chunk) {
+        const uint32_t n = (nslices - first < chunk) ? nslices - first : chunk;
+        const bool has_last = (first + n == nslices);
+        const uint64_t n_full = (nslices == 1) ? count_last : capacity;
+        const vkmr_status st = reduce_launch(S(s), digests + (uint64_t)first * capacity, n, n_full, has_last ? count_last : capacity, height,
+                                             reinterpret_cast<Node*>(scratch_dev), roots + first);
+        if (st != VKMR_OK) return st;
+    }
+    return VKMR_OK;
+}
+
+size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
+{
+    if (nslices == 0) nslices = 1;
+    // runs longer than 32768 slices are reduced in chunks (see vkmr_hip_reduce_slices_async): the
+    // scratch must hold the largest chunk's passes -- the full chunks and the shorter last one
+    const uint32_t full = nslices > 32768u ? 32768u : nslices;
+    const uint32_t rest = nslices > 32768u ? nslices % 32768u : 0u;
+    size_t cells = (size_t)scratch_cells(capacity, full) * full;
+    if (rest) {
+        const size_t c2 = (size_t)scratch_cells(capacity, rest) * rest;
+        cells = c2 > cells ? c2 : cells;
+    }
+    return cells * sizeof(vkmr_digest);
 }
 
 size_t vkmr_hip_reduce_levels_scratch_bytes(uint64_t count)
