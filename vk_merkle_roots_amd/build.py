@@ -69,7 +69,7 @@ def build_host(force=False):
     os.makedirs(BIN, exist_ok=True)
     hdrs = _tree(HOST, (".hpp", ".h")) + [os.path.join(ROOT, "include", "vkmr_hip.h")]
     cxx = os.environ.get("CXX", "g++")
-    flags = ["-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", HOST]
+    flags = ["-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", HOST]
     built = []
 
     def need(target, srcs):

@@ -3,6 +3,9 @@
 
 #include <cstring>
 #include <iostream>
+#include <thread>
+
+#include "fork_join.hpp"
 
 #include "stream_pack.hpp"
 
@@ -69,6 +72,69 @@ PackResult Batch::PushLines(const char* buf, size_t len, bool final, size_t max_
     r = PackLines(reinterpret_cast<const uint8_t*>(buf), len, final, m_data, m_words, m_cap_words, m_meta + m_count, room);
     m_count += r.strings;
     m_words += r.words;
+    m_bytes += r.bytes;
+    return r;
+}
+
+PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, ForkJoin& pool)
+{
+    PackResult r = {0, 0, 0, 0, 0};
+    const unsigned threads = pool.Width();
+    if (!(*this) || threads < 2 || len < (1u << 20)) return r;
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(buf);
+    // only whole lines: a span that is not final stops at its last '\n'
+    size_t usable = len;
+    if (!final) {
+        const void* nl = memrchr(b, '\n', len);
+        usable = nl ? (size_t)(static_cast<const uint8_t*>(nl) - b) + 1 : 0;
+    }
+    if (usable < (1u << 20)) return r;
+    // 1. parts that end after a '\n'
+    struct Part { size_t lo, hi; LineCount c; };
+    std::vector<Part> parts;
+    const size_t per = usable / threads;
+    size_t lo = 0;
+    for (unsigned t = 0; t < threads && lo < usable; ++t) {
+        size_t hi = (t + 1 == threads) ? usable : per * (t + 1);
+        if (hi < lo) hi = lo;
+        if (hi < usable) {
+            const void* nl = memchr(b + hi, '\n', usable - hi);
+            hi = nl ? (size_t)(static_cast<const uint8_t*>(nl) - b) + 1 : usable;
+        }
+        if (hi > lo) parts.push_back({lo, hi, {0, 0, 0, 0, false}});
+        lo = hi;
+    }
+    // 2. measure every part
+    pool.Run((unsigned)parts.size(), [&](unsigned t) { parts[t].c = CountLines(b + parts[t].lo, parts[t].hi - parts[t].lo); });
+    // 3. leading parts that fit entirely
+    size_t room = m_cap_count - m_count;
+    if (room > max_strings) room = max_strings;
+    size_t k = 0, words = 0, strings = 0;
+    std::vector<size_t> w0, c0;
+    for (; k < parts.size(); ++k) {
+        const LineCount& c = parts[k].c;
+        if (c.too_long || strings + c.strings > room || m_words + words + c.words > m_cap_words ||
+            m_words + words + c.words > 0xFFFFFFFFull)
+            break;
+        w0.push_back(m_words + words);
+        c0.push_back(m_count + strings);
+        words += c.words;
+        strings += c.strings;
+    }
+    if (k == 0) return r;
+    // 4. pack them at their prefix offsets
+    pool.Run((unsigned)k, [&](unsigned t) {
+        PackLines(b + parts[t].lo, parts[t].hi - parts[t].lo, true, m_data, w0[t], m_cap_words, m_meta + c0[t], parts[t].c.strings);
+    });
+    for (size_t t = 0; t < k; ++t) {
+        r.bytes += parts[t].c.bytes;
+        r.empties += parts[t].c.empties;
+    }
+    r.consumed = parts[k - 1].hi;
+    r.strings = strings;
+    r.words = words;
+    m_count += strings;
+    m_words += words;
     m_bytes += r.bytes;
     return r;
 }

@@ -52,6 +52,12 @@ public:
     // `max_strings`; stops early when the batch is full.  Returns what PackLines reports
     // (bytes consumed, strings appended, ...).
     struct PackResult PushLines(const char* buf, size_t len, bool final, size_t max_strings);
+    // Parallel form of PushLines for large spans: the span is cut into pool.Width() parts at line
+    // ends, the parts are measured in parallel, the leading parts that fit the batch (and
+    // `max_strings`) are packed in parallel at their prefix offsets.  Returns what was consumed
+    // and appended (possibly nothing: the caller then falls back to PushLines).  Every part
+    // but the last of a final span ends in '\n'.
+    struct PackResult PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, class ForkJoin& pool);
     // Drops the last `count` strings (reference Batch::Pop, src/vkmr/Batches.cpp:123-125).
     void Pop(size_t count);
 

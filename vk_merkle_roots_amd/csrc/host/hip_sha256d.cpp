@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
+#include "fork_join.hpp"
 #include "util.hpp"
 
 namespace vkmr {
@@ -21,6 +23,11 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_BATCH_BYTES")) c.batch_bytes = (size_t)atol(e);
     if (const char* e = getenv("VKMR_MAX_INFLIGHT")) c.max_inflight = (size_t)atol(e);
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
+    if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
+    if (c.pack_threads == 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        c.pack_threads = hw == 0 ? 1u : (hw > 8u ? 8u : hw);
+    }
     if (c.slice_log2 < 1) c.slice_log2 = 1;
     if (c.slice_log2 > 40) c.slice_log2 = 40;   // beyond HBM: the allocation fails and Add() reports it
     if (c.batch_bytes < 4096) c.batch_bytes = 4096;
@@ -81,6 +88,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
         }
         m_devs.push_back(std::move(pd));
     }
+    m_pool.reset(new ForkJoin(cfg.pack_threads > 1 ? cfg.pack_threads - 1 : 0));
     m_mappings = Mappings::New(cfg.verbose);
     m_reductions = Reductions::New(devices.empty() ? 0 : devices.front(), cfg.verbose);
     if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
@@ -89,6 +97,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
 HipSha256D::Instance::~Instance()
 {
     // ops first (they hold batches and slices), then the pools and streams
+    m_pool.reset();
     m_mappings.reset();
     m_reductions.reset();
     m_batch = Batch();
@@ -190,7 +199,8 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
             if (!StartSliceAndBatch()) return false;
         }
         Slice& slice = m_slices.Current();
-        const PackResult r = m_batch.PushLines(buf + pos, len - pos, final, slice.Available());
+        PackResult r = m_batch.PushLinesParallel(buf + pos, len - pos, final, slice.Available(), *m_pool);
+        if (r.consumed == 0) r = m_batch.PushLines(buf + pos, len - pos, final, slice.Available());
         slice.Reserve(r.strings);
         tally->items += r.strings;
         tally->bytes += r.bytes;

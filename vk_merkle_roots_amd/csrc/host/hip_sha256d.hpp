@@ -18,12 +18,13 @@ namespace vkmr {
 
 struct HipConfig {
     uint32_t slice_log2 = 23;        // digests per slice: 2^23 = 256 MiB, the reference's slice (SHA-256vk.cpp:23)
-    size_t batch_bytes = 32u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
-                                     // :247-248); fed from stdin, 8-32 MiB batches pipeline best on MI355X (host reader
-                                     // ~4 GB/s, copies and kernels hidden behind it): 0.55 s vs 0.77 s per 2^25 strings
+    size_t batch_bytes = 64u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
+                                     // :247-248); fed from stdin, 32-64 MiB batches pipeline best on MI355X (copies
+                                     // and kernels hide behind the host packer; measured sweep in DESIGN.md 5)
     size_t max_inflight = 4;         // mappings in flight before Add() blocks on the oldest
+    unsigned pack_threads = 0;       // threads packing large input spans (0 = min(8, hardware threads))
     bool verbose = false;            // per-op log lines like the reference prints
-    static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_MAX_INFLIGHT, VKMR_VERBOSE
+    static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_MAX_INFLIGHT, VKMR_PACK_THREADS, VKMR_VERBOSE
 };
 
 class HipSha256D {
@@ -71,6 +72,7 @@ private:
     Batch m_batch;
     std::unique_ptr<Mappings> m_mappings;
     std::unique_ptr<Reductions> m_reductions;
+    std::unique_ptr<class ForkJoin> m_pool;   // packs large input spans in parallel
     bool m_ok;
 };
 

@@ -39,6 +39,7 @@ public:
 
 private:
     bool Fill();
+    size_t ReadSome(char* dst, size_t n);   // fread, or a copy out of the mapping
 
     FILE* m_fp;
     bool m_owner, m_eof;
@@ -46,6 +47,10 @@ private:
     std::vector<char> m_buf;
     size_t m_pos, m_end;
     std::string m_carry;
+    // a regular file on the stream is mapped instead of read (GetBlock then hands out spans of the
+    // mapping itself: no copy at all between the page cache and the packer)
+    const char* m_map = nullptr;
+    size_t m_map_len = 0, m_map_pos = 0;
 };
 
 }  // namespace vkmr

@@ -37,6 +37,27 @@ PackResult PackLines(const uint8_t* buf, size_t len, bool final, uint32_t* data,
     return r;
 }
 
+LineCount CountLines(const uint8_t* buf, size_t len)
+{
+    LineCount c = {0, 0, 0, 0, false};
+    size_t pos = 0;
+    while (pos < len) {
+        const uint8_t* nl = static_cast<const uint8_t*>(memchr(buf + pos, '\n', len - pos));
+        const size_t end = nl ? (size_t)(nl - buf) : len;
+        const size_t n = end - pos;
+        if (n == 0) {
+            ++c.empties;
+        } else {
+            if (n > 0xFFFFFFFFull) c.too_long = true;
+            ++c.strings;
+            c.words += (n + 3u) / 4u;
+            c.bytes += n;
+        }
+        pos = nl ? end + 1 : end;
+    }
+    return c;
+}
+
 }  // namespace vkmr
 
 extern "C" {

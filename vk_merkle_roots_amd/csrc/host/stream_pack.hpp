@@ -29,4 +29,9 @@ struct PackResult {
 PackResult PackLines(const uint8_t* buf, size_t len, bool final, uint32_t* data, uint64_t first_word,
                      uint64_t data_capacity_words, vkmr_metadata* meta, uint64_t meta_capacity);
 
+// What PackLines would append for buf[0,len) with final = true, without writing anything
+// (first pass of the parallel packer).
+struct LineCount { uint64_t strings, words, bytes, empties; bool too_long; };
+LineCount CountLines(const uint8_t* buf, size_t len);
+
 }  // namespace vkmr
