@@ -159,3 +159,35 @@ def test_device_listing_with_several_devices(native):
     assert r.returncode == 1
     for want in (b"* CPU", b"* hip:0", b"* hip:1", b"* hip:all"):
         assert want in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"VKMR_PACK_THREADS": "8", "VKMR_BATCH_MB": "16", "VKMR_SLICE_LOG2": "18"},
+    {"VKMR_PACK_THREADS": "3", "VKMR_BATCH_MB": "64"},
+    {"VKMR_PACK_THREADS": "16", "VKMR_INPUT_SPAN_MB": "4", "VKMR_BATCH_MB": "8", "VKMR_SLICE_LOG2": "19"},
+    {"VKMR_PACK_THREADS": "1"},
+])
+def test_hip_backend_mapped_file_and_parallel_packer(native, golden, tmp_path, env):
+    """stdin redirected from a regular file (mapped) with the fork-join packer: spans cut at line ends,
+    parts measured and packed in parallel, batch/slice boundaries falling inside spans."""
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    path = tmp_path / "g3.txt"
+    path.write_bytes(golden_stream(native, s))
+    e = dict(os.environ)
+    e.update(env)
+    with open(path, "rb") as f:
+        r = subprocess.run([tool(native, "vkmr"), "hip:0"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+    res = [LINE.match(l) for l in r.stdout.decode().splitlines()]
+    m = [x for x in res if x][-1].groupdict()
+    assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"]), env
+    assert r.stderr.count(b"Read an empty string?") == 1
+
+
+def test_cpu_backend_mapped_file(native, golden, tmp_path):
+    s = golden["streams"]["G4_rndm_42_4096_4096"]
+    path = tmp_path / "g4.txt"
+    path.write_bytes(golden_stream(native, s))
+    with open(path, "rb") as f:
+        r = subprocess.run([tool(native, "vkmr"), "CPU"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert s["root"] in r.stdout.decode()
