@@ -65,3 +65,13 @@ def test_front_end_under_asan_ubsan(native, oracle, tmp_path):
         want_root, want_count, _ = oracle.root_of_stream(s)
         out = [l for l in r.stdout.decode().splitlines() if "computed root" in l]
         assert (not out) if want_count == 0 else (want_root in out[0])
+
+
+def test_fork_join_pool_under_tsan(tmp_path):
+    """The packer's thread pool and the two-pass parallel packing scheme under ThreadSanitizer."""
+    host = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc", "host")
+    exe = str(tmp_path / "fj_tsan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I", host, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "fork_join_test.cpp"), os.path.join(host, "stream_pack.cpp"), "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and r.stdout.startswith(b"ok "), (r.stdout, r.stderr[-1500:])
