@@ -191,3 +191,17 @@ def test_cpu_backend_mapped_file(native, golden, tmp_path):
     with open(path, "rb") as f:
         r = subprocess.run([tool(native, "vkmr"), "CPU"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert s["root"] in r.stdout.decode()
+
+
+def test_very_long_lines_pipe_and_mapped_file(native, oracle, tmp_path):
+    """Lines longer than the reader's 16 MiB block (pipe: the buffer grows) and than the 32 MiB span of a
+    mapped file (the span is extended to the line's end)."""
+    data = b"head\n" + b"q" * (40 << 20) + b"\nmid\n" + b"r" * (70 << 20) + b"\ntail"
+    want, cnt, nb = oracle.root_of_stream(data)
+    r, out, m = run_vkmr(native, "CPU", data)
+    assert m and (m["root"], int(m["items"]), int(m["bytes"])) == (want, cnt, nb)
+    path = tmp_path / "long.txt"
+    path.write_bytes(data)
+    with open(path, "rb") as f:
+        r = subprocess.run([tool(native, "vkmr"), "CPU"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert want in r.stdout.decode() and f"(of {cnt} item(s), {nb} byte(s))" in r.stdout.decode()
