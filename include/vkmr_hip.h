@@ -43,6 +43,7 @@ typedef int vkmr_status;
 #define VKMR_ERR_NO_DEVICE (-2)
 #define VKMR_ERR_OOM      (-3) /* VK_ERROR_OUT_OF_DEVICE_MEMORY / _HOST_MEMORY              */
 #define VKMR_ERR_HIP      (-4) /* any other HIP runtime failure                              */
+#define VKMR_ERR_COMM     (-5) /* RCCL failure, or librccl could not be loaded               */
 
 /* ---- wire structs: identical layout to the reference's device structs ---- */
 
@@ -137,8 +138,11 @@ VKMR_API vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s,
  * a lone leaf is hashed with itself, the CPU backend's rule)
  * for a single slice.  Requires ceil(count / 2^height) == 1.
  *   digests_dev  count cells, read only (the reference reduces in place)
- *   scratch_dev  vkmr_hip_reduce_scratch_bytes(count) bytes of device memory
+ *   scratch_dev  vkmr_hip_reduce_scratch_bytes(count) bytes of device memory; the size function is an
+ *                upper bound for EVERY run of at most `count` digests, so scratch sized for a slice's
+ *                capacity serves any shorter slice (may be NULL for count <= 128)
  *   root_dev     one cell in device memory receiving the root
+ * height is at most 63.
  */
 VKMR_API vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s,
                                            const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
@@ -192,14 +196,63 @@ VKMR_API vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s,
 VKMR_API size_t vkmr_hip_reduce_levels_scratch_bytes(uint64_t count);
 
 /*
- * COMBINE: duplicate-last Merkle root over n >= 1 slice roots given in slice order
- * (host memory), always at least one level -- the rule of CpuSha256D::Root that
- * the reference applies to the slice roots on the CPU (CpuSha256DforReductions,
- * src/vkmr/Reductions.cpp:56-69, :703-712).  Runs on device `dev`.  For n == 1 the
- * reference prints the slice root itself (src/vkmr/Reductions.cpp:692-701); callers
- * do the same and do not call combine.
+ * COMBINE: duplicate-last Merkle root over n >= 1 slice roots given in slice order, always
+ * at least one level -- the rule of CpuSha256D::Root that the reference applies to the slice
+ * roots on the CPU (CpuSha256DforReductions, src/vkmr/Reductions.cpp:56-69, :703-712).  Here
+ * the roots stay in HBM (where the reductions or the gather below left them) and the combine is
+ * one more launch on the caller's stream: no allocation, no synchronisation.  For n == 1 the
+ * reference prints the slice root itself (src/vkmr/Reductions.cpp:692-701); callers do the same
+ * and do not call combine.
+ *   scratch_dev  vkmr_hip_reduce_scratch_bytes(n) bytes; may be NULL for n <= 128
  */
-VKMR_API vkmr_status vkmr_hip_combine(int dev, const vkmr_digest* roots_host, uint32_t n, vkmr_digest* out_host);
+VKMR_API vkmr_status vkmr_hip_combine_async(int dev, vkmr_stream s, const vkmr_digest* roots_dev, uint32_t n,
+                                            void* scratch_dev, vkmr_digest* root_dev);
+
+/* ---- multi-GPU: slices sharded over devices, ONE gather of the sub-tree roots --------------
+ *
+ * The reference drives one device and collects slice roots on the host: each Reduction copies
+ * its 32-byte root into a host-visible buffer (src/vkmr/Reductions.cpp:125-145, :537-540) and
+ * ReductionsImpl::WaitFor feeds them, in slice order, to CpuSha256DforReductions (:56-69,
+ * :703-712).  With slices sharded over the GPUs of a node that collection is a single RCCL
+ * all-gather over xGMI (32 bytes per slice), after which any rank holds every root and runs
+ * vkmr_hip_combine_async.  Two ways to form the communicator: one process driving every GPU
+ * (the C++ front end's "hip:all"), or one process per GPU (bench.py under torch.distributed.run;
+ * the 128-byte id travels over whatever channel the host program already has).
+ * librccl is loaded on the first communicator, never by single-GPU runs.
+ */
+typedef struct vkmr_comm_s* vkmr_comm;
+#define VKMR_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+
+/* One process, ndev devices: rank i of the communicator is devs[i]. */
+VKMR_API vkmr_status vkmr_hip_comm_init_all(const int* devs, int ndev, vkmr_comm* out);
+/* One process per device: rank 0 creates the id, every rank joins with the same id. */
+VKMR_API vkmr_status vkmr_hip_comm_create_id(void* id /* VKMR_COMM_ID_BYTES */);
+VKMR_API vkmr_status vkmr_hip_comm_init_rank(int dev, const void* id, int nranks, int rank, vkmr_comm* out);
+VKMR_API vkmr_status vkmr_hip_comm_destroy(vkmr_comm c);
+/* Ranks in the communicator and how many of them this process drives. */
+VKMR_API vkmr_status vkmr_hip_comm_size(vkmr_comm c, int* nranks, int* nlocal);
+
+/*
+ * GATHER: every rank contributes `per_rank` roots; when the call has completed on streams[i],
+ * all_dev[i] (nranks * per_rank cells) holds rank r's roots at [r * per_rank, (r + 1) * per_rank).
+ * The three arrays have one entry per LOCAL rank (one entry in a one-process-per-GPU program).
+ * Ranks with fewer roots pad to per_rank; the padding is never read by the combine.
+ * Issued as one ncclAllGather per local rank (grouped), enqueued on the given streams: ordered
+ * after the reductions that produce roots_dev[i] when those ran on the same stream.
+ */
+VKMR_API vkmr_status vkmr_hip_gather_roots_async(vkmr_comm c, const vkmr_stream* streams,
+                                                 const vkmr_digest* const* roots_dev, uint32_t per_rank,
+                                                 vkmr_digest* const* all_dev);
+
+/*
+ * Reorders gathered roots into slice order when slices were dealt round-robin (slice k on rank
+ * (k-1) % nranks, Slices::New -- the reference numbers slices 1, 2, ... in stream order,
+ * src/vkmr/Slices.h:371): out[k] = gathered[(k % nranks) * per_rank + k / nranks], k < total.
+ * With one slice per rank (bench.py) the gathered order already is the slice order.
+ */
+VKMR_API vkmr_status vkmr_hip_roots_in_slice_order_async(int dev, vkmr_stream s, const vkmr_digest* gathered_dev,
+                                                         uint32_t nranks, uint32_t per_rank, uint32_t total,
+                                                         vkmr_digest* out_dev);
 
 /* Canonical lower-case hex of a digest cell (hash_to_string + print_bytes,
  * src/vkmr/SHA-256plus.cpp:453-469, src/vkmr/Debug.cpp:38-46).  hex holds 65 bytes. */

@@ -144,6 +144,18 @@ def native():
     return build
 
 
+def build_virt_devices():
+    """tests/_build/libvirt_devices.so: the LD_PRELOAD test double that shows one GPU as several
+    (tests/c/virt_devices.cpp).  Test infrastructure; never part of the product."""
+    src = os.path.join(ROOT, "tests", "c", "virt_devices.cpp")
+    out = os.path.join(ROOT, "tests", "_build", "libvirt_devices.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-shared", "-fPIC", src, "-o", out,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 @pytest.fixture(scope="session")
 def gpu(native):
     import vk_merkle_roots_amd as vk

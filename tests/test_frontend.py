@@ -10,6 +10,14 @@ import pytest
 LINE = re.compile(r"^(?P<name>\S+): computed root \(of (?P<items>\d+) item\(s\), (?P<bytes>\d+) byte\(s\)\) => (?P<root>[0-9a-f]{64}) in [0-9.e+-]+$")
 
 
+def virtual_devices_env(k):
+    """Environment that makes the box's one GPU look like k GPUs to the unmodified product binaries:
+    the LD_PRELOAD test double tests/c/virt_devices.cpp (device enumeration + a same-process stand-in for
+    RCCL, which itself refuses several ranks on one physical GPU)."""
+    from conftest import build_virt_devices
+    return {"LD_PRELOAD": build_virt_devices(), "VKMR_TEST_VIRTUAL_DEVICES": str(k)}
+
+
 def tool(native, name):
     return os.path.join(os.path.dirname(native.HIP_LIB), "bin", name)
 
@@ -129,6 +137,44 @@ def test_hip_string_larger_than_batch_is_refused(native):
 
 
 @pytest.mark.gpu
+def test_hip_slices_and_scratch_are_recycled(native, golden):
+    """README.md:113 (the reference's first to-do): 256 slices of 2^12 stream through at most max_inflight + 1
+    slice allocations; the memory of a retired slice, its reduction's scratch and the batches are re-used."""
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    r, out, m = run_vkmr(native, "hip:0", golden_stream(native, s), {"VKMR_SLICE_LOG2": "12", "VKMR_VERBOSE": "1", "VKMR_MAX_INFLIGHT": "4"})
+    assert m and m["root"] == s["root"]
+    assert sum(1 for l in out if l.startswith("Looking for")) <= 5
+    summary = [l for l in out if l.startswith("Allocations:")][0]
+    slices, batches, scratch = [int(x) for x in re.findall(r"(\d+) (?:slice\(s\),|batch\(es\),|reduction)", summary)]
+    assert slices <= 5 and batches <= 6 and scratch <= 5, summary
+    assert "for 256 slice(s)" in summary
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget", ["1", "2"])
+def test_hip_capped_slice_budget_waits_instead_of_halting(native, golden, budget):
+    """HBM "capped" to one or two slices: Add() blocks on the oldest reduction and takes over its slice
+    (the reference halts: SHA-256vk.cpp:396-399); the root is still the golden one."""
+    for name, log2 in (("G3_rndm_42_1048576_127", "14"), ("G6_rndm_7_1000_300", "6")):
+        s = golden["streams"][name]
+        r, out, m = run_vkmr(native, "hip:0", golden_stream(native, s),
+                             {"VKMR_SLICE_LOG2": log2, "VKMR_SLICE_BUDGET": budget, "VKMR_BATCH_BYTES": "200000"})
+        assert r.returncode == 0, r.stderr[-400:]
+        assert m and (int(m["items"]), m["root"]) == (s["items"], s["root"]), (name, budget)
+        assert sum(1 for l in out if l.startswith("Looking for")) <= int(budget)
+
+
+@pytest.mark.gpu
+def test_hip_long_strings_grow_the_batches(native, golden):
+    """Strings of 2 KiB on average: the front end moves to larger batches (a launch needs ~2^19 strings to fill
+    the chip) -- same root."""
+    s = golden["streams"]["G4_rndm_42_4096_4096"]
+    r, out, m = run_vkmr(native, "hip:0", golden_stream(native, s), {"VKMR_BATCH_BYTES": "1000000", "VKMR_BATCH_MAX_MB": "256", "VKMR_VERBOSE": "1"})
+    assert m and m["root"] == s["root"]
+    assert any("batches of" in l for l in out)
+
+
+@pytest.mark.gpu
 def test_hip_slice_allocation_failure_is_reported_not_fatal(native):
     """A slice larger than HBM cannot be allocated: Add() refuses, nothing is printed, exit code 0
     (reference: allocation failure => Add returns false => loop ends, src/vkmr/Vkmr.cpp:44-52)."""
@@ -138,14 +184,19 @@ def test_hip_slice_allocation_failure_is_reported_not_fatal(native):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [
-    {"VKMR_HIP_VIRTUAL_DEVICES": "2", "VKMR_SLICE_LOG2": "12", "VKMR_BATCH_BYTES": "50000"},
-    {"VKMR_HIP_VIRTUAL_DEVICES": "4", "VKMR_SLICE_LOG2": "16", "VKMR_BATCH_MB": "1", "VKMR_MAX_INFLIGHT": "3"},
-    {"VKMR_HIP_VIRTUAL_DEVICES": "3", "VKMR_SLICE_LOG2": "10", "VKMR_BATCH_BYTES": "8192"},
+@pytest.mark.parametrize("ndev,env", [
+    (2, {"VKMR_SLICE_LOG2": "12", "VKMR_BATCH_BYTES": "50000"}),
+    (4, {"VKMR_SLICE_LOG2": "16", "VKMR_BATCH_MB": "1", "VKMR_MAX_INFLIGHT": "3"}),
+    (3, {"VKMR_SLICE_LOG2": "10", "VKMR_BATCH_BYTES": "8192"}),
+    (8, {"VKMR_SLICE_LOG2": "17", "VKMR_BATCH_MB": "2"}),        # 8 slices of 2^17, one per device (config 4's shape in small)
+    (5, {"VKMR_SLICE_LOG2": "19", "VKMR_BATCH_MB": "4"}),        # fewer slices (2) than devices
+    (2, {"VKMR_SLICE_LOG2": "8", "VKMR_BATCH_BYTES": "30000", "VKMR_SLICE_BUDGET": "1"}),
 ])
-def test_hip_all_shards_slices_over_devices(native, golden, env):
-    """"hip:all": slices round-robin over every device, per-device streams and batch pools, roots combined in
-    slice order.  VKMR_HIP_VIRTUAL_DEVICES enumerates the one GPU several times so the path runs here."""
+def test_hip_all_shards_slices_over_devices(native, golden, ndev, env):
+    """"hip:all": slices round-robin over every device, per-device streams, batch and slice pools, one root array
+    per device, ONE gather of the arrays, combine in slice order on the first device.  The box has one GPU: the
+    LD_PRELOAD test double shows it k times to the unmodified binaries (see virtual_devices_env)."""
+    env = dict(env, **virtual_devices_env(ndev))
     for name in ("G2_rndm_1712489279_1024_127", "G3_rndm_42_1048576_127", "G6_rndm_7_1000_300", "L7_three"):
         s = golden["streams"][name]
         r, out, m = run_vkmr(native, "hip:all", golden_stream(native, s), env)
@@ -155,7 +206,7 @@ def test_hip_all_shards_slices_over_devices(native, golden, env):
 
 @pytest.mark.gpu
 def test_device_listing_with_several_devices(native):
-    r, out, m = run_vkmr(native, None, b"a\n", {"VKMR_HIP_VIRTUAL_DEVICES": "2"})
+    r, out, m = run_vkmr(native, None, b"a\n", virtual_devices_env(2))
     assert r.returncode == 1
     for want in (b"* CPU", b"* hip:0", b"* hip:1", b"* hip:all"):
         assert want in r.stderr

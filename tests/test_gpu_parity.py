@@ -286,3 +286,50 @@ def test_proof_rejects_bad_index(gpu):
     d = gpu.alloc(32 * 8)
     with pytest.raises(vk.VkmrError):
         gpu.proof(d, 8, 3, 8)
+
+
+# ---- scratch budget (short runs must not outgrow the scratch sized for the full count) ----
+
+def _guarded_scratch(gpu, nbytes, guard=1 << 20):
+    buf = gpu.alloc(nbytes + guard)
+    import vk_merkle_roots_amd as vk
+    vk.check(gpu.lib.vkmr_hip_memset_async(gpu.index, gpu.stream, buf.at(nbytes), 0xA5, guard), "memset")
+    gpu.sync()
+    return buf, lambda: bool((gpu.download(buf, guard, dtype=np.uint8, offset=nbytes) == 0xA5).all())
+
+
+def test_scratch_budget_reduce_slices_one_short_slice(gpu, oracle):
+    """capacity 2^20, one slice of 2^20 - 256 nodes: its own schedule collapses one level in the first pass
+    (786240 cells) where the full capacity's collapses two."""
+    rng = np.random.default_rng(21)
+    cap, last = 1 << 20, (1 << 20) - 256
+    leaves = rng.integers(0, 2**32, size=(last, 8), dtype=np.uint32)
+    d_in = gpu.upload(leaves)
+    nbytes = gpu.lib.vkmr_hip_reduce_slices_scratch_bytes(cap, 1)
+    d_scratch, intact = _guarded_scratch(gpu, nbytes)
+    d_roots = gpu.alloc(32)
+    gpu.reduce_slices_async(d_in, 1, cap, last, 20, d_scratch, d_roots)
+    got = gpu.download(d_roots, 32)
+    assert intact()
+    assert (got == oracle.reduce_height(leaves, 20)).all()
+
+
+def test_scratch_budget_proof_sibling_subtrees(gpu, oracle):
+    """count = 3 * 2^20 - 256, index 0: the level-21 sibling is a sub-tree of 2^20 - 256 leaves."""
+    import vk_merkle_roots_amd as vk
+    rng = np.random.default_rng(22)
+    n, height = 3 * (1 << 20) - 256, 22
+    leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+    d_in = gpu.upload(leaves)
+    d_scratch, intact = _guarded_scratch(gpu, gpu.lib.vkmr_hip_reduce_scratch_bytes(n))
+    d_sib, d_root = gpu.alloc(32 * height), gpu.alloc(32)
+    want_root = oracle.reduce_height(leaves, height)
+    h = vk.host_lib()
+    for index in (0, n - 1, (1 << 21) + 5):
+        vk.check(gpu.lib.vkmr_hip_proof_async(gpu.index, gpu.stream, d_in.ptr, n, height, index, d_scratch.ptr, d_sib.ptr, d_root.ptr), "proof")
+        sib = gpu.download(d_sib, 32 * height).reshape(-1, 8)
+        assert intact(), index
+        assert (gpu.download(d_root, 32) == want_root).all()
+        folded = np.zeros(8, dtype=np.uint32)
+        h.vkmr_host_cpu_fold_proof(leaves[index].ctypes.data, index, np.ascontiguousarray(sib).ctypes.data, height, folded.ctypes.data)
+        assert (folded == want_root).all(), index

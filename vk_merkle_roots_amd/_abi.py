@@ -9,7 +9,8 @@ import os
 from .build import HIP_LIB, HOST_LIB
 
 OK, NOT_READY = 0, 1
-ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_HIP = -1, -2, -3, -4
+ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_HIP, ERR_COMM = -1, -2, -3, -4, -5
+COMM_ID_BYTES = 128
 
 
 class Metadata(C.Structure):          # vkmr_metadata == VkSha256Metadata
@@ -53,7 +54,14 @@ SIGNATURES = {
                                        C.c_void_p]),
     "vkmr_hip_reduce_levels_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_reduce_levels_scratch_bytes": (C.c_size_t, [C.c_uint64]),
-    "vkmr_hip_combine": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vkmr_hip_combine_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "vkmr_hip_comm_init_all": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "vkmr_hip_comm_create_id": (C.c_int, [C.c_void_p]),
+    "vkmr_hip_comm_init_rank": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "vkmr_hip_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vkmr_hip_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vkmr_hip_gather_roots_async": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "vkmr_hip_roots_in_slice_order_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "vkmr_hip_digest_hex": (None, [C.c_void_p, C.c_char_p]),
     "vkmr_hip_last_error": (C.c_char_p, []),
     "vkmr_hip_kernel_info": (C.c_char_p, []),

@@ -39,7 +39,8 @@ bool Batch::Push(const char* p, size_t n)
 {
     if (!(*this)) return false;
     const size_t nw = WordCount(n);
-    if (m_count + 1 > m_cap_count || m_words + nw > m_cap_words || n > 0xFFFFFFFFull) return false;
+    // start is a 32-bit word index and size a 32-bit byte count (vkmr_metadata)
+    if (m_count + 1 > m_cap_count || m_words + nw > m_cap_words || n > 0xFFFFFFFFull || m_words > 0xFFFFFFFFull) return false;
     m_meta[m_count].start = (uint32_t)m_words;
     m_meta[m_count].size = (uint32_t)n;
     if (nw) {
@@ -151,23 +152,38 @@ void Batch::Pop(size_t count)
 Batches::Batches(int dev, size_t data_bytes)
     : m_dev(dev), m_words(data_bytes / 4), m_count(data_bytes / sizeof(vkmr_digest)), m_live(0), m_next(0)
 {
+    if (m_words > 0xFFFFFFFFull) m_words = 0xFFFFFFFFull;   // vkmr_metadata::start is a 32-bit word index
     if (m_count == 0) m_count = 1;
+}
+
+void Batches::Free(Buffers& b)
+{
+    vkmr_hip_host_free(b.data);
+    vkmr_hip_host_free(b.meta);
+    vkmr_hip_device_free(m_dev, b.ddata);
+    vkmr_hip_device_free(m_dev, b.dmeta);
 }
 
 Batches::~Batches()
 {
-    for (auto& b : m_free) {
-        vkmr_hip_host_free(b.data);
-        vkmr_hip_host_free(b.meta);
-        vkmr_hip_device_free(m_dev, b.ddata);
-        vkmr_hip_device_free(m_dev, b.dmeta);
-    }
+    for (auto& b : m_free) Free(b);
+}
+
+void Batches::Reshape(size_t data_bytes, size_t meta_count)
+{
+    size_t words = data_bytes / 4;
+    if (words > 0xFFFFFFFFull) words = 0xFFFFFFFFull;
+    if (words == 0 || meta_count == 0 || (words == m_words && meta_count == m_count)) return;
+    m_words = words;
+    m_count = meta_count;
+    for (auto& b : m_free) Free(b);   // idle buffers of the old shape
+    m_free.clear();
 }
 
 Batch Batches::New()
 {
     Batch b;
-    Buffers buf = {nullptr, nullptr, nullptr, nullptr};
+    Buffers buf = {nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (!m_free.empty()) {
         buf = m_free.back();
         m_free.pop_back();
@@ -177,18 +193,18 @@ Batch Batches::New()
                         vkmr_hip_host_alloc(m_count * sizeof(vkmr_metadata), &h2) == VKMR_OK &&
                         vkmr_hip_device_alloc(m_dev, m_words * 4, &d1) == VKMR_OK &&
                         vkmr_hip_device_alloc(m_dev, m_count * sizeof(vkmr_metadata), &d2) == VKMR_OK;
-        if (!ok) {
-            std::cerr << "Failed to allocate a batch: " << vkmr_hip_last_error() << std::endl;
+        if (!ok) {   // the caller waits for a mapping to retire and tries again, or reports the failure
             vkmr_hip_host_free(h1); vkmr_hip_host_free(h2);
             vkmr_hip_device_free(m_dev, d1); vkmr_hip_device_free(m_dev, d2);
             return b;
         }
         buf = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1),
-               static_cast<vkmr_metadata*>(d2)};
+               static_cast<vkmr_metadata*>(d2), m_words, m_count};
+        ++m_allocations;
     }
     b.m_owner = this; b.m_dev = m_dev;
     b.m_data = buf.data; b.m_meta = buf.meta; b.m_ddata = buf.ddata; b.m_dmeta = buf.dmeta;
-    b.m_cap_words = m_words; b.m_cap_count = m_count;
+    b.m_cap_words = buf.words; b.m_cap_count = buf.count;
     b.m_number = m_next++;
     ++m_live;
     return b;
@@ -196,7 +212,11 @@ Batch Batches::New()
 
 void Batches::Recycle(Batch& b)
 {
-    m_free.push_back({b.m_data, b.m_meta, b.m_ddata, b.m_dmeta});
+    Buffers buf = {b.m_data, b.m_meta, b.m_ddata, b.m_dmeta, b.m_cap_words, b.m_cap_count};
+    if (buf.words == m_words && buf.count == m_count)
+        m_free.push_back(buf);
+    else
+        Free(buf);   // shape changed since this batch was handed out
     --m_live;
 }
 

@@ -94,11 +94,17 @@ public:
     Batch New();                 // a fresh or recycled batch; falsy when allocation fails
     void Recycle(Batch& b);      // called by Batch::Release
     size_t InCirculation() const { return m_live; }
+    size_t Allocations() const { return m_allocations; }
+    size_t DataBytes() const { return m_words * 4; }
+    // Batches handed out from now on hold `data_bytes` of data and `meta_count` strings; buffers of
+    // the old shape are released as they come back.
+    void Reshape(size_t data_bytes, size_t meta_count);
 
 private:
-    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; };
+    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; size_t words, count; };
+    void Free(Buffers& b);
     int m_dev;
-    size_t m_words, m_count, m_live;
+    size_t m_words, m_count, m_live, m_allocations = 0;
     uint32_t m_next;
     std::vector<Buffers> m_free;
 };

@@ -21,7 +21,9 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_SLICE_LOG2")) c.slice_log2 = (uint32_t)atoi(e);
     if (const char* e = getenv("VKMR_BATCH_MB")) c.batch_bytes = (size_t)atol(e) << 20;
     if (const char* e = getenv("VKMR_BATCH_BYTES")) c.batch_bytes = (size_t)atol(e);
+    if (const char* e = getenv("VKMR_BATCH_MAX_MB")) c.batch_bytes_max = (size_t)atol(e) << 20;
     if (const char* e = getenv("VKMR_MAX_INFLIGHT")) c.max_inflight = (size_t)atol(e);
+    if (const char* e = getenv("VKMR_SLICE_BUDGET")) c.slice_budget = (size_t)atol(e);
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
@@ -31,6 +33,10 @@ HipConfig HipConfig::FromEnv()
     if (c.slice_log2 < 1) c.slice_log2 = 1;
     if (c.slice_log2 > 40) c.slice_log2 = 40;   // beyond HBM: the allocation fails and Add() reports it
     if (c.batch_bytes < 4096) c.batch_bytes = 4096;
+    // a packed batch addresses its data by 32-bit word index (vkmr_metadata::start)
+    if (c.batch_bytes > (size_t)0xFFFFFFFFull * 4u) c.batch_bytes = (size_t)0xFFFFFFFFull * 4u;
+    if (c.batch_bytes_max > (size_t)0xFFFFFFFFull * 4u) c.batch_bytes_max = (size_t)0xFFFFFFFFull * 4u;
+    if (c.batch_bytes_max < c.batch_bytes) c.batch_bytes_max = c.batch_bytes;
     if (c.max_inflight < 1) c.max_inflight = 1;
     return c;
 }
@@ -68,7 +74,7 @@ std::unique_ptr<HipSha256D::Instance> HipSha256D::Get(const ISha256D::name_type&
 }
 
 HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices, const HipConfig& cfg)
-    : ISha256D(name), m_cfg(cfg), m_slices(devices, (size_t)1 << cfg.slice_log2), m_ok(true)
+    : ISha256D(name), m_cfg(cfg), m_slices(devices, (size_t)1 << cfg.slice_log2, cfg.slice_budget ? cfg.slice_budget : cfg.max_inflight + 1), m_ok(true)
 {
     for (int d : devices) {
         PerDevice pd;
@@ -90,7 +96,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
     }
     m_pool.reset(new ForkJoin(cfg.pack_threads > 1 ? cfg.pack_threads - 1 : 0));
     m_mappings = Mappings::New(cfg.verbose);
-    m_reductions = Reductions::New(devices.empty() ? 0 : devices.front(), cfg.verbose);
+    m_reductions = Reductions::New(devices, (size_t)1 << cfg.slice_log2, cfg.verbose);
     if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
 }
 
@@ -127,8 +133,51 @@ void HipSha256D::Instance::Account(std::vector<Slice>&& retired)
         if (slice.IsFilled()) {
             if (m_cfg.verbose) std::cout << "Slice #" << slice.Number() << " has been filled." << std::endl;
             const int dev = slice.Device();
-            m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, Dev(dev).reduce_stream);
+            if (m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, Dev(dev).reduce_stream) != VKMR_OK) m_ok = false;
         }
+    }
+    if (m_mappings->Failed()) m_ok = false;
+}
+
+// Blocks until the oldest piece of in-flight work has retired and given its buffers back
+// (the reference's first to-do: "block ... and re-use the associated batch (or slice),
+// rather than halting", README.md:113).  false: nothing is in flight, waiting cannot help.
+bool HipSha256D::Instance::WaitForMemory()
+{
+    if (m_reductions->WaitOne()) return true;
+    if (m_mappings->InFlight()) {
+        Account(m_mappings->WaitUntilAtMost(m_mappings->InFlight() - 1));   // may fill a slice and start its reduction
+        return true;
+    }
+    return false;
+}
+
+bool HipSha256D::Instance::NewBatch(int dev)
+{
+    for (;;) {
+        m_batch = Dev(dev).batches->New();
+        if (m_batch) return true;
+        if (!m_ok || !WaitForMemory()) {
+            std::cerr << "Failed to allocate a batch: " << vkmr_hip_last_error() << std::endl;
+            return false;
+        }
+    }
+}
+
+// A launch of the map kernel fills the chip from about 2^19 strings on.  Batches are sized in bytes
+// (64 MiB by default: best behind the host reader for short strings), so when the strings are long
+// the following batches are made larger, up to batch_bytes_max.
+void HipSha256D::Instance::AdaptBatchSize(const Batch& sent)
+{
+    if (sent.Count() == 0) return;
+    const size_t avg = sent.Size() / sent.Count() + 4;
+    size_t want = avg << 19;
+    want = (want + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
+    if (want > m_cfg.batch_bytes_max) want = m_cfg.batch_bytes_max;
+    Batches& pool = *Dev(sent.Device()).batches;
+    if (want > pool.DataBytes() + pool.DataBytes() / 2) {
+        if (m_cfg.verbose) std::cout << "Strings average " << avg - 4 << " bytes: batches of " << (want >> 20) << " MiB from now on." << std::endl;
+        pool.Reshape(want, (size_t)1 << 20);
     }
 }
 
@@ -138,15 +187,26 @@ bool HipSha256D::Instance::MapCurrent()
     if (m_batch.Empty() || !slice) return true;
     if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
     PerDevice& pd = Dev(slice.Device());
+    AdaptBatchSize(m_batch);
     return m_mappings->Map(std::move(m_batch), slice.Sub(), pd.map_stream) == VKMR_OK;
 }
 
 bool HipSha256D::Instance::StartSliceAndBatch()
 {
-    Slice& slice = m_slices.New();
-    if (!slice) return false;
-    m_batch = Dev(slice.Device()).batches->New();
-    return static_cast<bool>(m_batch);
+    // no memory for the next slice (HBM full, or the slice budget used up): wait for the oldest
+    // reduction to retire and take over its slice, instead of halting (reference SHA-256vk.cpp:396-399
+    // halts; README.md:113 is the to-do this implements)
+    for (;;) {
+        bool budget_hit = false;
+        Slice& slice = m_slices.New(&budget_hit);
+        if (slice) break;
+        if (!m_ok || !WaitForMemory()) {
+            std::cerr << "Failed to allocate slice " << m_slices.LastNumber() + 1 << ": "
+                      << (budget_hit ? "slice budget used up and nothing in flight" : vkmr_hip_last_error()) << std::endl;
+            return false;
+        }
+    }
+    return NewBatch(m_slices.Current().Device());
 }
 
 bool HipSha256D::Instance::Add(const char* bytes, size_t size)
@@ -171,8 +231,7 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
         // batch full: map it and continue in a fresh one on the same device
         const int dev = m_slices.Current().Device();
         if (!MapCurrent()) return (m_ok = false);
-        m_batch = Dev(dev).batches->New();
-        if (!m_batch || !m_batch.Push(bytes, size)) {
+        if (!NewBatch(dev) || !m_batch.Push(bytes, size)) {
             // refuse this string only: what was added before still has a root
             // (the caller stops reading and prints it, reference Vkmr.cpp:44-55)
             std::cerr << "A string of " << size << " byte(s) does not fit an empty batch." << std::endl;
@@ -214,8 +273,7 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
             const int dev = slice.Device();
             const bool was_empty = m_batch.Empty();
             if (!MapCurrent()) return (m_ok = false);
-            m_batch = Dev(dev).batches->New();
-            if (!m_batch) return (m_ok = false);
+            if (!NewBatch(dev)) return (m_ok = false);
             if (was_empty) {   // even an empty batch cannot take the next line
                 const char* nl = static_cast<const char*>(memchr(buf + pos, '\n', len - pos));
                 std::cerr << "A string of " << (nl ? (size_t)(nl - (buf + pos)) : len - pos)
@@ -234,6 +292,7 @@ ISha256D::out_type HipSha256D::Instance::Root()
     const bool single = m_slices.LastNumber() <= 1;
     if (!MapCurrent()) return "";
     Account(m_mappings->WaitFor());
+    if (!m_ok) return "";   // a mapping or a reduction failed: there is no root
     // every remaining slice (at most the last, partial one): slice #1 alone is
     // reduced over its own count, any other to full capacity height
     // (reference Reductions.cpp:471; SHA-256vk.cpp:301-311)
@@ -244,9 +303,16 @@ ISha256D::out_type HipSha256D::Instance::Root()
         if (!s || s.Count() == 0) continue;
         const uint32_t height = (single && number == 1) ? tree_height(s.Count()) : m_cfg.slice_log2;
         const int dev = s.Device();
-        m_reductions->Reduce(std::move(s), height, Dev(dev).reduce_stream);
+        if (m_reductions->Reduce(std::move(s), height, Dev(dev).reduce_stream) != VKMR_OK) return "";
     }
-    return m_reductions->WaitFor();
+    const out_type root = m_reductions->WaitFor();
+    if (m_cfg.verbose) {
+        size_t batches = 0;
+        for (const auto& pd : m_devs) batches += pd.batches->Allocations();
+        std::cout << "Allocations: " << m_slices.Allocations() << " slice(s), " << batches << " batch(es), " << m_reductions->Allocations()
+                  << " reduction scratch buffer(s) for " << m_slices.LastNumber() << " slice(s)." << std::endl;
+    }
+    return root;
 }
 
 }  // namespace vkmr

@@ -21,10 +21,17 @@ struct HipConfig {
     size_t batch_bytes = 64u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
                                      // :247-248); fed from stdin, 32-64 MiB batches pipeline best on MI355X (copies
                                      // and kernels hide behind the host packer; measured sweep in DESIGN.md 5)
+    size_t batch_bytes_max = 1u << 30;  // long strings: batches grow until they hold about 2^19 strings, up to this many
+                                     // bytes (a 64 MiB batch of 2 KiB strings is 32 k strings = 512 wavefronts for
+                                     // 1024 SIMDs; the map kernel needs >= ~0.5 M strings per launch to fill the chip)
     size_t max_inflight = 4;         // mappings in flight before Add() blocks on the oldest
+    size_t slice_budget = 0;         // slices resident per device at most (0 = max_inflight + 1: the one being filled
+                                     // plus one per mapping in flight); when used up, Add() blocks on the oldest
+                                     // reduction and re-uses its slice instead of allocating another
     unsigned pack_threads = 0;       // threads packing large input spans (0 = min(8, hardware threads))
     bool verbose = false;            // per-op log lines like the reference prints
-    static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_MAX_INFLIGHT, VKMR_PACK_THREADS, VKMR_VERBOSE
+    static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_BATCH_MAX_MB, VKMR_MAX_INFLIGHT,
+                                     // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_VERBOSE
 };
 
 class HipSha256D {
@@ -65,6 +72,9 @@ private:
     bool MapCurrent();                                   // dispatches m_batch into the current slice's pending reservations
     void Account(std::vector<Slice>&& retired);          // retired sub-slices -> fill counts -> reductions
     bool StartSliceAndBatch();
+    bool NewBatch(int dev);                              // m_batch <- a batch of `dev`, waiting for one to retire if need be
+    bool WaitForMemory();                                // blocks on the oldest reduction / mapping; false when nothing is in flight
+    void AdaptBatchSize(const Batch& sent);              // long strings: larger batches from now on
 
     HipConfig m_cfg;
     std::vector<PerDevice> m_devs;

@@ -62,6 +62,7 @@ public:
     std::vector<slice_type> WaitFor() override { return Retire(true, 0); }
     std::vector<slice_type> WaitUntilAtMost(size_t limit) override { return Retire(true, limit); }
     size_t InFlight() const override { return m_inflight.size(); }
+    bool Failed() const override { return m_failed; }
 
 private:
     vkmr_event Event(int dev)
@@ -89,6 +90,14 @@ private:
                 ++it;
                 continue;
             }
+            if (st < 0) {   // the device reported an error: these digests do not exist
+                std::cerr << "Mapping for slice #" << it->sub.Number() << " failed: " << vkmr_hip_last_error() << std::endl;
+                m_failed = true;
+                m_spare.emplace_back(it->dev, it->begin);
+                m_spare.emplace_back(it->dev, it->done);
+                it = m_inflight.erase(it);
+                continue;
+            }
             if (m_verbose) {
                 float ms = 0.f;
                 vkmr_hip_event_elapsed_ms(it->dev, it->begin, it->done, &ms);
@@ -104,6 +113,7 @@ private:
     }
 
     bool m_verbose;
+    bool m_failed = false;
     std::vector<Mapping> m_inflight;
     std::vector<std::pair<int, vkmr_event>> m_spare;
 };

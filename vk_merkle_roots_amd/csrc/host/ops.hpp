@@ -34,25 +34,42 @@ public:
     // reference's first to-do, README.md:113); returns the retired sub-slices.
     virtual std::vector<slice_type> WaitUntilAtMost(size_t limit) = 0;
     virtual size_t InFlight() const = 0;
+    // true once a mapping has failed on the device (its sub-slice is never reported back, so the
+    // run cannot produce a root)
+    virtual bool Failed() const = 0;
 
     static std::unique_ptr<Mappings> New(bool verbose);
 };
 
 // Reduces slices of device memory to their sub-tree roots and combines the roots.
+//
+// Slice roots stay in HBM, one array per device (slice k, dealt to device (k-1) % D, is entry
+// (k-1) / D of its device's array); a pinned host mirror receives each root for the log lines.
+// Scratch buffers and events are pooled per device, so a long stream reduces slice after slice
+// without allocating.  The final combine runs on the first device: with one device directly over
+// its root array, with several after ONE RCCL all-gather of the arrays (vkmr_hip_gather_roots_async)
+// -- the step the reference does by reading every root back and hashing on the CPU
+// (src/vkmr/Reductions.cpp:56-69, :703-712).
 class Reductions {
 public:
     typedef Slice slice_type;
     virtual ~Reductions() = default;
 
-    // Starts the reduction of a slice through `height` levels; the slice's memory is
-    // released when the reduction retires.
+    // Starts the reduction of a slice through `height` levels; the slice's memory goes back to
+    // its pool when the reduction retires.  When the device has no memory for another scratch
+    // buffer, blocks on the oldest reduction in flight and re-uses its buffers.
     virtual HipResult Reduce(slice_type&&, uint32_t height, vkmr_stream) = 0;
     virtual void Update() = 0;
+    // Blocks until the oldest reduction in flight has retired; false when none is in flight.
+    virtual bool WaitOne() = 0;
+    virtual size_t InFlight() const = 0;
+    virtual size_t Allocations() const = 0;   // scratch buffers allocated so far (pool bookkeeping, for the log)
     // Waits for every reduction, combines the slice roots in slice order and returns
     // the hex root ("" on failure or when nothing was reduced).
     virtual ISha256D::out_type WaitFor() = 0;
 
-    static std::unique_ptr<Reductions> New(int combine_device, bool verbose);
+    // devices: every device slices are dealt to, in dealing order; capacity: digests per slice.
+    static std::unique_ptr<Reductions> New(std::vector<int> devices, size_t capacity, bool verbose);
 };
 
 }  // namespace vkmr

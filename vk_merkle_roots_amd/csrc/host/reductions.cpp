@@ -1,9 +1,11 @@
 // reductions.cpp -- in-flight reductions and the final combine (reference
 // src/vkmr/Reductions.cpp:621-713).  A reduction is one vkmr_hip_reduce_async on the
-// op's stream followed by a 32-byte copy of the root into pinned host memory (the
-// reference's vkCmdCopyBuffer, Reductions.cpp:537-540) and an event.
+// op's stream, its root written into the device's root array, a 32-byte copy of it
+// into the pinned host mirror (the reference's vkCmdCopyBuffer, Reductions.cpp:537-540)
+// and an event.  See ops.hpp for the layout of the root arrays and the pools.
+#include <algorithm>
+#include <cstring>
 #include <iostream>
-#include <map>
 
 #include "cpu_sha256d.hpp"
 #include "ops.hpp"
@@ -11,70 +13,91 @@
 namespace vkmr {
 namespace {
 
+// What one reduction in flight needs besides its slice; recycled through PerDevice::spare.
+struct Resources {
+    void* scratch = nullptr;
+    vkmr_event begin = nullptr, done = nullptr;
+};
+
 struct Reduction {
     Slice slice;
-    void* scratch = nullptr;
-    vkmr_digest* root_dev = nullptr;
-    vkmr_digest* root_host = nullptr;
-    vkmr_event begin = nullptr, done = nullptr;
+    Resources res;
+    size_t device_index = 0;   // index into m_devs
+    uint32_t slot = 0;         // entry of the device's root array
+};
+
+struct PerDevice {
     int dev = -1;
+    vkmr_stream stream = nullptr;        // the stream of this device's reductions (as given to Reduce)
+    vkmr_digest* roots_dev = nullptr;    // HBM: root of the device's j-th slice at [j]
+    vkmr_digest* roots_host = nullptr;   // pinned mirror
+    uint32_t roots_cap = 0, roots_used = 0;
+    std::vector<Resources> spare;
 };
 
 class ReductionsImpl : public Reductions {
 public:
-    ReductionsImpl(int combine_device, bool verbose) : m_combine_dev(combine_device), m_verbose(verbose) {}
+    ReductionsImpl(std::vector<int> devices, size_t capacity, bool verbose)
+        : m_capacity(capacity), m_scratch_bytes(vkmr_hip_reduce_scratch_bytes(capacity)), m_verbose(verbose)
+    {
+        for (int d : devices) {
+            PerDevice pd;
+            pd.dev = d;
+            m_devs.push_back(pd);
+        }
+    }
+
     ~ReductionsImpl() override
     {
         for (auto& r : m_inflight) {
-            vkmr_hip_event_wait(r.dev, r.done);
-            Free(r);
+            vkmr_hip_event_wait(m_devs[r.device_index].dev, r.res.done);
+            m_devs[r.device_index].spare.push_back(r.res);
         }
+        m_inflight.clear();   // slices go back to their pool
+        for (auto& d : m_devs) {
+            for (auto& res : d.spare) FreeResources(d.dev, res);
+            vkmr_hip_device_free(d.dev, d.roots_dev);
+            vkmr_hip_host_free(d.roots_host);
+        }
+        if (m_comm) vkmr_hip_comm_destroy(m_comm);
     }
 
     HipResult Reduce(slice_type&& slice, uint32_t height, vkmr_stream stream) override
     {
         if (!slice || slice.Count() == 0) return VKMR_OK;
-        Reduction r;
-        r.dev = slice.Device();
-        void *scratch = nullptr, *rd = nullptr, *rh = nullptr;
-        HipResult st = vkmr_hip_device_alloc(r.dev, vkmr_hip_reduce_scratch_bytes(slice.Count()), &scratch);
-        if (st == VKMR_OK) st = vkmr_hip_device_alloc(r.dev, sizeof(vkmr_digest), &rd);
-        if (st == VKMR_OK) st = vkmr_hip_host_alloc(sizeof(vkmr_digest), &rh);
-        if (st == VKMR_OK) st = vkmr_hip_event_create(r.dev, &r.begin);
-        if (st == VKMR_OK) st = vkmr_hip_event_create(r.dev, &r.done);
-        r.scratch = scratch;
-        r.root_dev = static_cast<vkmr_digest*>(rd);
-        r.root_host = static_cast<vkmr_digest*>(rh);
-        if (st == VKMR_OK) st = vkmr_hip_event_record(r.dev, r.begin, stream);
-        if (st == VKMR_OK) st = vkmr_hip_reduce_async(r.dev, stream, slice.Cells(), slice.Count(), height, r.scratch, r.root_dev);
-        if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(r.dev, stream, r.root_host, r.root_dev, sizeof(vkmr_digest));
-        if (st == VKMR_OK) st = vkmr_hip_event_record(r.dev, r.done, stream);
+        const HipResult st = Dispatch(slice, height, stream);
         if (st != VKMR_OK) {
             std::cerr << "Failed to dispatch a reduction: " << vkmr_hip_last_error() << std::endl;
-            Free(r);
-            return st;
+            m_failed = true;   // a slice without a root: the run has no root either
         }
-        r.slice = std::move(slice);
-        m_inflight.push_back(std::move(r));
-        return VKMR_OK;
+        return st;
     }
 
-    void Update() override { Retire(false); }
+    void Update() override { Retire(false, (size_t)-1); }
+
+    bool WaitOne() override
+    {
+        if (m_inflight.empty()) return false;
+        Retire(true, m_inflight.size() - 1);
+        return true;
+    }
+
+    size_t InFlight() const override { return m_inflight.size(); }
+    size_t Allocations() const override { return m_allocations; }
 
     ISha256D::out_type WaitFor() override
     {
-        Retire(true);
-        if (m_results.empty()) return "";
-        if (m_results.size() == 1) return digest_words_to_hex(m_results.begin()->second.data);
-        // slice roots in slice order 1..n (reference Reductions.cpp:703-712); any gap is a failure
-        std::vector<vkmr_digest> roots;
-        uint32_t expect = 1;
-        for (const auto& kv : m_results) {
-            if (kv.first != expect++) return "";
-            roots.push_back(kv.second);
+        Retire(true, 0);
+        if (m_failed || m_dispatched == 0) return "";
+        // every slice 1..n must have been reduced: n roots for slice numbers up to n
+        // (reference: roots looked up by slice number 1..n, Reductions.cpp:703-712)
+        if (m_retired != m_dispatched || m_last_number != m_dispatched) {
+            std::cerr << "Reduced " << m_retired << " of " << m_last_number << " slice(s); no root." << std::endl;
+            return "";
         }
+        if (m_dispatched == 1) return digest_words_to_hex(m_devs[0].roots_host[0].data);   // Reductions.cpp:692-701
         vkmr_digest top;
-        if (vkmr_hip_combine(m_combine_dev, roots.data(), (uint32_t)roots.size(), &top) != VKMR_OK) {
+        if (Combine(&top) != VKMR_OK) {
             std::cerr << "Failed to combine the slice roots: " << vkmr_hip_last_error() << std::endl;
             return "";
         }
@@ -82,48 +105,202 @@ public:
     }
 
 private:
-    void Free(Reduction& r)
+    void FreeResources(int dev, Resources& r)
     {
-        vkmr_hip_device_free(r.dev, r.scratch);
-        vkmr_hip_device_free(r.dev, r.root_dev);
-        vkmr_hip_host_free(r.root_host);
-        vkmr_hip_event_destroy(r.dev, r.begin);
-        vkmr_hip_event_destroy(r.dev, r.done);
-        r.scratch = nullptr; r.root_dev = nullptr; r.root_host = nullptr; r.begin = r.done = nullptr;
+        vkmr_hip_device_free(dev, r.scratch);
+        vkmr_hip_event_destroy(dev, r.begin);
+        vkmr_hip_event_destroy(dev, r.done);
+        r = Resources();
     }
 
-    void Retire(bool block)
+    // Scratch + events for one more reduction on device `di`: recycled, freshly allocated, or --
+    // when HBM has no room -- taken over from the oldest reduction once it has retired.
+    HipResult Acquire(size_t di, Resources* out)
+    {
+        PerDevice& d = m_devs[di];
+        for (;;) {
+            if (!d.spare.empty()) {
+                *out = d.spare.back();
+                d.spare.pop_back();
+                return VKMR_OK;
+            }
+            Resources r;
+            HipResult st = vkmr_hip_device_alloc(d.dev, m_scratch_bytes, &r.scratch);
+            if (st == VKMR_OK) st = vkmr_hip_event_create(d.dev, &r.begin);
+            if (st == VKMR_OK) st = vkmr_hip_event_create(d.dev, &r.done);
+            if (st == VKMR_OK) {
+                *out = r;
+                ++m_allocations;
+                return VKMR_OK;
+            }
+            FreeResources(d.dev, r);
+            if (st != VKMR_ERR_OOM || !WaitOne()) return st;
+        }
+    }
+
+    // Room for entry `slot` of the device's root array (grows by doubling; the reductions of this
+    // device are drained first, their roots copied over -- rare: 4096 slices fit before the first time).
+    HipResult EnsureRoots(size_t di, uint32_t slot)
+    {
+        PerDevice& d = m_devs[di];
+        if (slot < d.roots_cap) return VKMR_OK;
+        uint32_t cap = d.roots_cap ? d.roots_cap : 4096u;
+        while (cap <= slot) cap *= 2u;
+        void *nd = nullptr, *nh = nullptr;
+        HipResult st = vkmr_hip_device_alloc(d.dev, (size_t)cap * sizeof(vkmr_digest), &nd);
+        if (st == VKMR_OK) st = vkmr_hip_host_alloc((size_t)cap * sizeof(vkmr_digest), &nh);
+        if (st != VKMR_OK) {
+            vkmr_hip_device_free(d.dev, nd);
+            return st;
+        }
+        if (d.roots_cap) {
+            while (std::any_of(m_inflight.begin(), m_inflight.end(), [&](const Reduction& r) { return r.device_index == di; })) WaitOne();
+            std::memcpy(nh, d.roots_host, (size_t)d.roots_cap * sizeof(vkmr_digest));
+            st = vkmr_hip_memcpy_h2d_async(d.dev, d.stream, nd, nh, (size_t)d.roots_cap * sizeof(vkmr_digest));
+            if (st == VKMR_OK) st = vkmr_hip_stream_sync(d.dev, d.stream);
+            vkmr_hip_device_free(d.dev, d.roots_dev);
+            vkmr_hip_host_free(d.roots_host);
+        }
+        d.roots_dev = static_cast<vkmr_digest*>(nd);
+        d.roots_host = static_cast<vkmr_digest*>(nh);
+        d.roots_cap = cap;
+        return st;
+    }
+
+    HipResult Dispatch(slice_type& slice, uint32_t height, vkmr_stream stream)
+    {
+        size_t di = 0;
+        while (di < m_devs.size() && m_devs[di].dev != slice.Device()) ++di;
+        if (di == m_devs.size() || slice.Number() == 0) return VKMR_ERR_INVALID;
+        PerDevice& d = m_devs[di];
+        d.stream = stream;
+        Reduction r;
+        r.device_index = di;
+        r.slot = (uint32_t)((slice.Number() - 1) / m_devs.size());
+        HipResult st = EnsureRoots(di, r.slot);
+        if (st == VKMR_OK) st = Acquire(di, &r.res);
+        if (st != VKMR_OK) return st;
+        st = vkmr_hip_event_record(d.dev, r.res.begin, stream);
+        if (st == VKMR_OK) st = vkmr_hip_reduce_async(d.dev, stream, slice.Cells(), slice.Count(), height, r.res.scratch, d.roots_dev + r.slot);
+        if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, d.roots_host + r.slot, d.roots_dev + r.slot, sizeof(vkmr_digest));
+        if (st == VKMR_OK) st = vkmr_hip_event_record(d.dev, r.res.done, stream);
+        if (st != VKMR_OK) {
+            d.spare.push_back(r.res);
+            return st;
+        }
+        if (r.slot + 1 > d.roots_used) d.roots_used = r.slot + 1;
+        if (slice.Number() > m_last_number) m_last_number = slice.Number();
+        ++m_dispatched;
+        r.slice = std::move(slice);
+        m_inflight.push_back(std::move(r));
+        return VKMR_OK;
+    }
+
+    // Retires finished reductions, oldest first; with `block` waits until at most `keep` remain.
+    void Retire(bool block, size_t keep)
     {
         for (auto it = m_inflight.begin(); it != m_inflight.end();) {
-            HipResult st = vkmr_hip_event_query(it->dev, it->done);
-            if (st == VKMR_NOT_READY && block) st = vkmr_hip_event_wait(it->dev, it->done);
+            PerDevice& d = m_devs[it->device_index];
+            HipResult st = vkmr_hip_event_query(d.dev, it->res.done);
+            if (st == VKMR_NOT_READY && block && m_inflight.size() > keep) st = vkmr_hip_event_wait(d.dev, it->res.done);
             if (st == VKMR_NOT_READY) {
                 ++it;
                 continue;
             }
-            if (m_verbose) {
-                float ms = 0.f;
-                vkmr_hip_event_elapsed_ms(it->dev, it->begin, it->done, &ms);
-                std::cout << "Reduction #" << it->slice.Number() << " finished in " << ms << "ms." << std::endl;
-                std::cout << "#" << it->slice.Number() << ":" << digest_words_to_hex(it->root_host->data) << std::endl;
+            if (st < 0) {   // the device reported an error: this slice has no root
+                std::cerr << "Reduction #" << it->slice.Number() << " failed: " << vkmr_hip_last_error() << std::endl;
+                m_failed = true;
+            } else {
+                ++m_retired;
+                if (m_verbose) {
+                    float ms = 0.f;
+                    vkmr_hip_event_elapsed_ms(d.dev, it->res.begin, it->res.done, &ms);
+                    std::cout << "Reduction #" << it->slice.Number() << " finished in " << ms << "ms." << std::endl;
+                    std::cout << "#" << it->slice.Number() << ":" << digest_words_to_hex(d.roots_host[it->slot].data) << std::endl;
+                }
             }
-            m_results[it->slice.Number()] = *it->root_host;
-            Free(*it);
-            it = m_inflight.erase(it);   // the slice's memory is released here
+            d.spare.push_back(it->res);
+            it = m_inflight.erase(it);   // the slice's memory returns to its pool here
         }
     }
 
-    int m_combine_dev;
+    // Root over all slice roots, in slice order, on the first device.
+    HipResult Combine(vkmr_digest* top)
+    {
+        const uint32_t total = m_dispatched;
+        const size_t ndev = m_devs.size();
+        PerDevice& d0 = m_devs[0];
+        void *ordered = nullptr, *scratch = nullptr, *final_dev = nullptr, *final_host = nullptr;
+        std::vector<void*> gathered(ndev, nullptr);
+        HipResult st = VKMR_OK;
+        const vkmr_digest* roots = d0.roots_dev;
+        if (ndev > 1) {
+            // ONE all-gather of the per-device root arrays over RCCL, then slice order on device 0
+            uint32_t per_rank = 0;
+            for (const auto& d : m_devs) per_rank = std::max(per_rank, d.roots_used);
+            std::vector<vkmr_stream> streams;
+            std::vector<const vkmr_digest*> mine;
+            std::vector<vkmr_digest*> all;
+            if (!m_comm) {
+                std::vector<int> ids;
+                for (const auto& d : m_devs) ids.push_back(d.dev);
+                st = vkmr_hip_comm_init_all(ids.data(), (int)ids.size(), &m_comm);
+            }
+            for (size_t i = 0; i < ndev && st == VKMR_OK; ++i) {
+                PerDevice& d = m_devs[i];
+                if (!d.stream) {   // a device that got no slice still takes part in the collective
+                    st = vkmr_hip_stream_create(d.dev, &d.stream);
+                    m_own_streams.push_back(i);
+                }
+                if (st == VKMR_OK) st = EnsureRoots(i, per_rank - 1);   // every rank sends per_rank cells
+                if (st == VKMR_OK) st = vkmr_hip_device_alloc(d.dev, ndev * (size_t)per_rank * sizeof(vkmr_digest), &gathered[i]);
+                streams.push_back(d.stream);
+                mine.push_back(d.roots_dev);
+                all.push_back(static_cast<vkmr_digest*>(gathered[i]));
+            }
+            if (st == VKMR_OK) st = vkmr_hip_gather_roots_async(m_comm, streams.data(), mine.data(), per_rank, all.data());
+            if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, (size_t)total * sizeof(vkmr_digest), &ordered);
+            if (st == VKMR_OK)
+                st = vkmr_hip_roots_in_slice_order_async(d0.dev, d0.stream, all[0], (uint32_t)ndev, per_rank, total, static_cast<vkmr_digest*>(ordered));
+            roots = static_cast<const vkmr_digest*>(ordered);
+        }
+        if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, vkmr_hip_reduce_scratch_bytes(total), &scratch);
+        if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, sizeof(vkmr_digest), &final_dev);
+        if (st == VKMR_OK) st = vkmr_hip_host_alloc(sizeof(vkmr_digest), &final_host);
+        if (st == VKMR_OK) st = vkmr_hip_combine_async(d0.dev, d0.stream, roots, total, scratch, static_cast<vkmr_digest*>(final_dev));
+        if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d0.dev, d0.stream, final_host, final_dev, sizeof(vkmr_digest));
+        if (st == VKMR_OK) st = vkmr_hip_stream_sync(d0.dev, d0.stream);
+        for (size_t i = 1; i < ndev && st == VKMR_OK; ++i)   // the other ranks' side of the gather
+            if (m_devs[i].stream && gathered[i]) st = vkmr_hip_stream_sync(m_devs[i].dev, m_devs[i].stream);
+        if (st == VKMR_OK) std::memcpy(top, final_host, sizeof(vkmr_digest));
+        for (size_t i = 0; i < ndev; ++i) vkmr_hip_device_free(m_devs[i].dev, gathered[i]);
+        vkmr_hip_device_free(d0.dev, ordered);
+        vkmr_hip_device_free(d0.dev, scratch);
+        vkmr_hip_device_free(d0.dev, final_dev);
+        vkmr_hip_host_free(final_host);
+        for (size_t i : m_own_streams) {
+            vkmr_hip_stream_destroy(m_devs[i].dev, m_devs[i].stream);
+            m_devs[i].stream = nullptr;
+        }
+        m_own_streams.clear();
+        return st;
+    }
+
+    size_t m_capacity, m_scratch_bytes, m_allocations = 0;
     bool m_verbose;
+    bool m_failed = false;
+    uint32_t m_dispatched = 0, m_retired = 0, m_last_number = 0;
+    std::vector<PerDevice> m_devs;
     std::vector<Reduction> m_inflight;
-    std::map<uint32_t, vkmr_digest> m_results;
+    std::vector<size_t> m_own_streams;
+    vkmr_comm m_comm = nullptr;
 };
 
 }  // namespace
 
-std::unique_ptr<Reductions> Reductions::New(int combine_device, bool verbose)
+std::unique_ptr<Reductions> Reductions::New(std::vector<int> devices, size_t capacity, bool verbose)
 {
-    return std::unique_ptr<Reductions>(new ReductionsImpl(combine_device, verbose));
+    return std::unique_ptr<Reductions>(new ReductionsImpl(std::move(devices), capacity, verbose));
 }
 
 }  // namespace vkmr

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "reduce_plan.hpp"   // VKMR_PASS_WAVES, VKMR_PASS_MAXM and the host-side schedule
 #include "sha256d_device.hpp"
 
 using vkmr_dev::Node;
@@ -12,9 +13,6 @@ using vkmr_dev::Node;
 // ============================================================================
 // REDUCE
 // ============================================================================
-
-#define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel
-#define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass
 
 __device__ __forceinline__ uint64_t level_count(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
 
@@ -74,6 +72,10 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
                         l[i] = __shfl(X[i], src);
                         r[i] = __shfl(X[i], src + 1u);
                     }
+                    // the pending half was written by OTHER lanes of this wavefront (below, an
+                    // earlier chunk): order those LDS writes before these reads explicitly
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     if (lane < 32u) {
                         const Node a = pend[(k - 1) * 64 + 2 * lane];
                         const Node b = pend[(k - 1) * 64 + 2 * lane + 1];
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
 #pragma unroll
             for (int i = 0; i < 8; ++i) t.w[i] = X[i];
             pend[(k - 1) * 64 + lane] = t;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     const uint64_t jo = (base0 >> (m + 1)) + lane;

@@ -22,6 +22,7 @@ using vkmr_dev::Node;
 
 #include "map_kernel.hpp"
 #include "reduce_kernels.hpp"
+#include "reduce_plan.hpp"
 
 // ============================================================================
 // C ABI
@@ -53,25 +54,6 @@ static vkmr_status from_hip(hipError_t e, const char* what)
         if (st__ != VKMR_OK) return st__;                \
     } while (0)
 
-// VKMR_HIP_VIRTUAL_DEVICES=k (test facility): every physical GPU is enumerated k times, so that the
-// multi-device host paths ("hip:all": slices round-robin over devices, per-device streams and pools)
-// can be exercised on a single-GPU machine.  Device index d maps to physical GPU d % real.
-static int g_real_devices = -1;
-static int virtual_factor()
-{
-    static const int k = [] { const char* e = getenv("VKMR_HIP_VIRTUAL_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-    return k;
-}
-static inline int phys(int dev)
-{
-    if (g_real_devices < 0) {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-        g_real_devices = n;
-    }
-    return (g_real_devices > 0 && dev >= 0) ? dev % g_real_devices : dev;
-}
-
 static inline hipStream_t S(vkmr_stream s) { return reinterpret_cast<hipStream_t>(s); }
 static inline hipEvent_t E(vkmr_event e) { return reinterpret_cast<hipEvent_t>(e); }
 
@@ -102,8 +84,7 @@ vkmr_status vkmr_hip_device_count(int* count)
         fail(VKMR_OK, "hipGetDeviceCount", e);
         return VKMR_OK;
     }
-    g_real_devices = n;
-    *count = n * virtual_factor();
+    *count = n;
     return VKMR_OK;
 }
 
@@ -111,7 +92,7 @@ vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen)
 {
     if (!buf || buflen == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_name: null buffer");
     hipDeviceProp_t p;
-    VKMR_TRY(hipGetDeviceProperties(&p, phys(dev)));
+    VKMR_TRY(hipGetDeviceProperties(&p, dev));
     // some ROCm installs leave the marketing name empty: fall back to the ISA name
     snprintf(buf, buflen, "%s", p.name[0] ? p.name : p.gcnArchName);
     return VKMR_OK;
@@ -120,7 +101,7 @@ vkmr_status vkmr_hip_device_name(int dev, char* buf, size_t buflen)
 vkmr_status vkmr_hip_device_mem_info(int dev, size_t* free_bytes, size_t* total_bytes)
 {
     if (!free_bytes || !total_bytes) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_mem_info: null out pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipMemGetInfo(free_bytes, total_bytes));
     return VKMR_OK;
 }
@@ -128,7 +109,7 @@ vkmr_status vkmr_hip_device_mem_info(int dev, size_t* free_bytes, size_t* total_
 vkmr_status vkmr_hip_device_geometry(int dev, int* compute_units, int* wavefront)
 {
     hipDeviceProp_t p;
-    VKMR_TRY(hipGetDeviceProperties(&p, phys(dev)));
+    VKMR_TRY(hipGetDeviceProperties(&p, dev));
     if (compute_units) *compute_units = p.multiProcessorCount;
     if (wavefront) *wavefront = p.warpSize;
     return VKMR_OK;
@@ -154,7 +135,7 @@ vkmr_status vkmr_hip_host_free(void* p)
 vkmr_status vkmr_hip_device_alloc(int dev, size_t bytes, void** out)
 {
     if (!out || bytes == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_device_alloc: bad argument");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     void* p = nullptr;
     VKMR_TRY(hipMalloc(&p, bytes));
     *out = p;
@@ -164,7 +145,7 @@ vkmr_status vkmr_hip_device_alloc(int dev, size_t bytes, void** out)
 vkmr_status vkmr_hip_device_free(int dev, void* p)
 {
     if (!p) return VKMR_OK;
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipFree(p));
     return VKMR_OK;
 }
@@ -172,7 +153,7 @@ vkmr_status vkmr_hip_device_free(int dev, void* p)
 vkmr_status vkmr_hip_memset_async(int dev, vkmr_stream s, void* dst, int value, size_t bytes)
 {
     if (!dst) return fail(VKMR_ERR_INVALID, "vkmr_hip_memset_async: null pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipMemsetAsync(dst, value, bytes, S(s)));
     return VKMR_OK;
 }
@@ -180,7 +161,7 @@ vkmr_status vkmr_hip_memset_async(int dev, vkmr_stream s, void* dst, int value, 
 vkmr_status vkmr_hip_memcpy_h2d_async(int dev, vkmr_stream s, void* dst_dev, const void* src_host, size_t bytes)
 {
     if (!dst_dev || !src_host) return fail(VKMR_ERR_INVALID, "vkmr_hip_memcpy_h2d_async: null pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(s)));
     return VKMR_OK;
 }
@@ -188,7 +169,7 @@ vkmr_status vkmr_hip_memcpy_h2d_async(int dev, vkmr_stream s, void* dst_dev, con
 vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (!dst_host || !src_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_memcpy_d2h_async: null pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(s)));
     return VKMR_OK;
 }
@@ -196,7 +177,7 @@ vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst_host, co
 vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
 {
     if (!out) return fail(VKMR_ERR_INVALID, "vkmr_hip_stream_create: null out pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     hipStream_t s;
     VKMR_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *out = reinterpret_cast<vkmr_stream>(s);
@@ -206,14 +187,14 @@ vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
 vkmr_status vkmr_hip_stream_destroy(int dev, vkmr_stream s)
 {
     if (!s) return VKMR_OK;
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipStreamDestroy(S(s)));
     return VKMR_OK;
 }
 
 vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s)
 {
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipStreamSynchronize(S(s)));
     return VKMR_OK;
 }
@@ -221,7 +202,7 @@ vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s)
 vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out)
 {
     if (!out) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_create: null out pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     hipEvent_t e;
     VKMR_TRY(hipEventCreate(&e));
     *out = reinterpret_cast<vkmr_event>(e);
@@ -231,7 +212,7 @@ vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out)
 vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e)
 {
     if (!e) return VKMR_OK;
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipEventDestroy(E(e)));
     return VKMR_OK;
 }
@@ -239,7 +220,7 @@ vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e)
 vkmr_status vkmr_hip_event_record(int dev, vkmr_event e, vkmr_stream s)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_record: null event");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipEventRecord(E(e), S(s)));
     return VKMR_OK;
 }
@@ -247,7 +228,7 @@ vkmr_status vkmr_hip_event_record(int dev, vkmr_event e, vkmr_stream s)
 vkmr_status vkmr_hip_event_query(int dev, vkmr_event e)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_query: null event");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     hipError_t r = hipEventQuery(E(e));
     if (r == hipErrorNotReady) {
         (void)hipGetLastError();
@@ -259,7 +240,7 @@ vkmr_status vkmr_hip_event_query(int dev, vkmr_event e)
 vkmr_status vkmr_hip_event_wait(int dev, vkmr_event e)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_wait: null event");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipEventSynchronize(E(e)));
     return VKMR_OK;
 }
@@ -267,7 +248,7 @@ vkmr_status vkmr_hip_event_wait(int dev, vkmr_event e)
 vkmr_status vkmr_hip_stream_wait_event(int dev, vkmr_stream s, vkmr_event e)
 {
     if (!e) return fail(VKMR_ERR_INVALID, "vkmr_hip_stream_wait_event: null event");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipStreamWaitEvent(S(s), E(e), 0));
     return VKMR_OK;
 }
@@ -275,7 +256,7 @@ vkmr_status vkmr_hip_stream_wait_event(int dev, vkmr_stream s, vkmr_event e)
 vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end, float* ms)
 {
     if (!begin || !end || !ms) return fail(VKMR_ERR_INVALID, "vkmr_hip_event_elapsed_ms: null argument");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     VKMR_TRY(hipEventElapsedTime(ms, E(begin), E(end)));
     return VKMR_OK;
 }
@@ -288,7 +269,7 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     if (count == 0) return VKMR_OK;
     if (!meta_dev || !out_dev || (!data_dev && data_words != 0))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     // VKMR_MAP_VARIANT picks an alternative fetch mode / geometry for A/B timing; 0 = shipped.
     static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
@@ -300,7 +281,7 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
             const uint64_t fit = (uint64_t)(stage_words * 0.9) / avg_words;
             if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
         }
-        hipLaunchKernelGGL(kern, dim3((count + tile - 1) / tile), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)(((uint64_t)count + tile - 1) / tile)), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
     };
     // tiles of up to 2048 strings, smaller when the batch is short so that it still
     // spreads over the chip (>= ~1024 workgroups when it can)
@@ -308,7 +289,7 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     tile = tile < 256u ? 256u : (tile > 2048u ? 2048u : tile);
     static const int tile_override = [] { const char* e = getenv("VKMR_MAP_TILE"); return e ? atoi(e) : 0; }();   // experiments only
     if (tile_override >= 64 && tile_override <= 2048) tile = (uint32_t)tile_override & ~63u;
-    const uint32_t grid = (count + tile - 1) / tile;
+    const uint32_t grid = (uint32_t)(((uint64_t)count + tile - 1) / tile);   // count + tile can pass 2^32
     auto launch_direct = [&](bool fullfast) {
         if (fullfast) {
             if (tile >= 1024u)
@@ -345,60 +326,26 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
 
 // ---- reduce ---------------------------------------------------------------------
 
-static inline uint64_t ceil_shift(uint64_t n, unsigned k) { return (n + ((1ull << k) - 1ull)) >> k; }
+using vkmr_plan::ceil_shift;
+using vkmr_plan::next_step;
+typedef vkmr_plan::Step ReduceStep;
+using vkmr_plan::STEP_BULK;
+using vkmr_plan::STEP_COLLAPSE;
+using vkmr_plan::STEP_TAIL;
 
-// Levels a bulk pass collapses for n input nodes per slice: the largest m+1 (m <= MAXM)
-// that still leaves enough wavefronts (over all slices of the launch) to fill 256 CUs.
-static uint32_t pick_m(uint64_t n, uint32_t nslices)
-{
-    const uint64_t target_waves = 4096;
-    for (int m = VKMR_PASS_MAXM; m > 0; --m)
-        if (ceil_shift(n, 7 + m) * nslices >= target_waves && (128ull << m) <= n) return (uint32_t)m;
-    return 0;
-}
-
+// `height` levels must take `count` nodes to exactly one.  A tree over 2^64 leaves does not
+// exist, so heights beyond 63 are refused rather than special-cased.
 static bool height_ok(uint64_t count, uint32_t height)
 {
-    if (count == 0) return false;
-    if (height >= 64) return true;
+    if (count == 0 || height > 63) return false;
     return ceil_shift(count, height) == 1;
-}
-
-// One step of the reduction schedule for n nodes with `left` levels to go:
-//   bulk     n/128 >= 2048 wavefronts: reduce_pass_kernel, m+1 levels, every lane busy
-//   collapse 128 < n: reduce_collapse_kernel, up to 7 levels, one wavefront per CU slot
-//   tail     n <= 128: reduce_tail_kernel, one wavefront, all remaining levels
-struct ReduceStep { int kind; uint32_t levels; uint64_t n_out; };
-enum { STEP_BULK = 0, STEP_COLLAPSE = 1, STEP_TAIL = 2 };
-
-static ReduceStep next_step(uint64_t n, uint32_t left, uint32_t nslices)
-{
-    ReduceStep st;
-    if (n <= 128) {
-        st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
-    } else if (ceil_shift(n, 7) * nslices >= 2048) {
-        st.kind = STEP_BULK; st.levels = pick_m(n, nslices) + 1u; st.n_out = ceil_shift(n, st.levels);
-    } else {
-        st.kind = STEP_COLLAPSE; st.levels = 7; st.n_out = ceil_shift(n, 7);
-    }
-    return st;
-}
-
-// Scratch cells one slice needs when `nslices` slices are reduced together.
-static uint64_t scratch_cells(uint64_t count, uint32_t nslices)
-{
-    uint64_t n = count, total = 0;
-    for (int pass = 0; pass < 2 && n > 128; ++pass) {
-        n = next_step(n, 64, nslices).n_out;
-        total += n;
-    }
-    return total + 2;
 }
 
 size_t vkmr_hip_reduce_scratch_bytes(uint64_t count)
 {
-    // ping-pong: outputs of step 1 and step 2 (later steps are smaller)
-    return (size_t)scratch_cells(count, 1) * sizeof(vkmr_digest);
+    // ping-pong: outputs of step 1 and step 2 (later steps are smaller), for ANY run of at
+    // most `count` nodes -- see vkmr_plan::cells_upper_bound
+    return (size_t)vkmr_plan::cells_upper_bound(count, 1) * sizeof(vkmr_digest);
 }
 
 // Reduces `nslices` slices (n_full nodes each, the last n_last) through `height`
@@ -456,7 +403,7 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* dig
     if (!height_ok(count, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: height does not reduce count to one node");
     if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), 1, count, count, height,
                          reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
 }
@@ -470,7 +417,7 @@ vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s, const vkmr_digest* dige
     if (!height_ok(count, height)) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: height does not reduce count to one node");
     if (index >= count) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: index out of range");
     if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null scratch");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     const Node* leaves = reinterpret_cast<const Node*>(digests_dev);
     Node* sib = reinterpret_cast<Node*>(siblings_dev);
     for (uint32_t l = 0; l < height; ++l) {
@@ -504,7 +451,7 @@ vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_dige
     if (!height_ok(nslices == 1 ? count_last : capacity, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: height does not reduce a slice to one node");
     if (capacity > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     // grid.y carries the slice index: at most 32768 slices per launch sequence; longer runs go in
     // chunks on the same stream (the scratch is reused, the stream serialises them)
     const uint32_t chunk = 32768u;
@@ -528,9 +475,9 @@ size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
     // scratch must hold the largest chunk's passes -- the full chunks and the shorter last one
     const uint32_t full = nslices > 32768u ? 32768u : nslices;
     const uint32_t rest = nslices > 32768u ? nslices % 32768u : 0u;
-    size_t cells = (size_t)scratch_cells(capacity, full) * full;
+    size_t cells = (size_t)vkmr_plan::cells_upper_bound(capacity, full) * full;
     if (rest) {
-        const size_t c2 = (size_t)scratch_cells(capacity, rest) * rest;
+        const size_t c2 = (size_t)vkmr_plan::cells_upper_bound(capacity, rest) * rest;
         cells = c2 > cells ? c2 : cells;
     }
     return cells * sizeof(vkmr_digest);
@@ -548,7 +495,7 @@ vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_dige
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: null pointer");
     if (!height_ok(count, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: height does not reduce count to one node");
-    VKMR_TRY(hipSetDevice(phys(dev)));
+    VKMR_TRY(hipSetDevice(dev));
     const Node* in = reinterpret_cast<const Node*>(digests_dev);
     Node* bufA = reinterpret_cast<Node*>(scratch_dev);
     Node* bufB = bufA + ceil_shift(count, 1);
@@ -568,24 +515,18 @@ vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_dige
 
 // ---- combine --------------------------------------------------------------------
 
-vkmr_status vkmr_hip_combine(int dev, const vkmr_digest* roots_host, uint32_t n, vkmr_digest* out_host)
+static uint32_t combine_height(uint64_t n)
 {
-    if (!roots_host || !out_host || n == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_combine: bad argument");
-    VKMR_TRY(hipSetDevice(phys(dev)));
     uint32_t height = 1;   // at least one level: CpuSha256D::Root's do-while (SHA-256plus.cpp:515-547)
     while (ceil_shift(n, height) > 1) ++height;
-    const size_t scratch = vkmr_hip_reduce_scratch_bytes(n);
-    char* buf = nullptr;
-    const size_t in_bytes = (size_t)n * sizeof(vkmr_digest);
-    VKMR_TRY(hipMalloc(reinterpret_cast<void**>(&buf), in_bytes + scratch + sizeof(vkmr_digest)));
-    vkmr_digest* d_in = reinterpret_cast<vkmr_digest*>(buf);
-    void* d_scratch = buf + in_bytes;
-    vkmr_digest* d_root = reinterpret_cast<vkmr_digest*>(buf + in_bytes + scratch);
-    vkmr_status st = from_hip(hipMemcpy(d_in, roots_host, in_bytes, hipMemcpyHostToDevice), "hipMemcpy(roots)");
-    if (st == VKMR_OK) st = vkmr_hip_reduce_async(dev, nullptr, d_in, n, height, d_scratch, d_root);
-    if (st == VKMR_OK) st = from_hip(hipMemcpy(out_host, d_root, sizeof(vkmr_digest), hipMemcpyDeviceToHost), "hipMemcpy(root)");
-    (void)hipFree(buf);
-    return st;
+    return height;
+}
+
+vkmr_status vkmr_hip_combine_async(int dev, vkmr_stream s, const vkmr_digest* roots_dev, uint32_t n, void* scratch_dev,
+                                   vkmr_digest* root_dev)
+{
+    if (!roots_dev || !root_dev || n == 0) return fail(VKMR_ERR_INVALID, "vkmr_hip_combine_async: bad argument");
+    return vkmr_hip_reduce_async(dev, s, roots_dev, n, combine_height(n), scratch_dev, root_dev);
 }
 
 void vkmr_hip_digest_hex(const vkmr_digest* d, char* hex)
@@ -601,3 +542,5 @@ void vkmr_hip_digest_hex(const vkmr_digest* d, char* hex)
 }
 
 }  // extern "C"
+
+#include "comm_rccl.hpp"

@@ -219,10 +219,19 @@ class HipDevice:
         fn = self.lib.vkmr_hip_reduce_levels_scratch_bytes if levels_variant else self.lib.vkmr_hip_reduce_scratch_bytes
         return self.alloc(fn(count))
 
+    def combine_async(self, roots_buf, n, scratch_buf, root_buf, stream=None):
+        check(self.lib.vkmr_hip_combine_async(self.index, stream or self.stream, roots_buf.ptr, n, scratch_buf.ptr if scratch_buf else None,
+                                              root_buf.ptr), "vkmr_hip_combine_async")
+
     def combine(self, roots):
+        """Root ([8] uint32) over slice roots given as a host array, in slice order."""
         roots = np.ascontiguousarray(roots, dtype=np.uint32).reshape(-1, 8)
-        out = np.zeros(8, dtype=np.uint32)
-        check(self.lib.vkmr_hip_combine(self.index, roots.ctypes.data, roots.shape[0], out.ctypes.data), "vkmr_hip_combine")
+        d_in, d_root = self.upload(roots), self.alloc(32)
+        d_scratch = self.reduce_scratch(roots.shape[0])
+        self.combine_async(d_in, roots.shape[0], d_scratch, d_root)
+        out = self.download(d_root, 32)
+        for b in (d_in, d_root, d_scratch):
+            b.free()
         return out
 
     # -- conveniences used by tests ------------------------------------------------
