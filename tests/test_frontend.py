@@ -131,9 +131,19 @@ def test_hip_backend_empty_input(native):
 
 @pytest.mark.gpu
 def test_hip_string_larger_than_batch_is_refused(native):
-    r, out, m = run_vkmr(native, "hip:0", b"a\n" + b"b" * 10000 + b"\nc\n", {"VKMR_BATCH_BYTES": "4096"})
+    r, out, m = run_vkmr(native, "hip:0", b"a\n" + b"b" * 10000 + b"\nc\n", {"VKMR_BATCH_BYTES": "4096", "VKMR_BATCH_MAX_MB": "0"})
     assert b"does not fit an empty batch" in r.stderr
     assert m and int(m["items"]) == 1   # the loop stops at the refused string, like the reference (Vkmr.cpp:44-47)
+
+
+@pytest.mark.gpu
+def test_hip_string_larger_than_batch_grows_the_batches(native, oracle):
+    """Batches start at 64 MiB here but 256 MiB in the reference: a string the reference would take is not refused,
+    the batches grow up to VKMR_BATCH_MAX_MB instead."""
+    data = b"a\n" + b"b" * 10000 + b"\nc\n" + b"d" * 70000 + b"\ne\n"
+    want, cnt, nb = oracle.root_of_stream(data)
+    r, out, m = run_vkmr(native, "hip:0", data, {"VKMR_BATCH_BYTES": "4096"})
+    assert m and (m["root"], int(m["items"]), int(m["bytes"])) == (want, cnt, nb), r.stderr[-300:]
 
 
 @pytest.mark.gpu

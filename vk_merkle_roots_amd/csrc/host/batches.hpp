@@ -96,6 +96,7 @@ public:
     size_t InCirculation() const { return m_live; }
     size_t Allocations() const { return m_allocations; }
     size_t DataBytes() const { return m_words * 4; }
+    size_t MetaCount() const { return m_count; }
     // Batches handed out from now on hold `data_bytes` of data and `meta_count` strings; buffers of
     // the old shape are released as they come back.
     void Reshape(size_t data_bytes, size_t meta_count);

@@ -171,6 +171,7 @@ void HipSha256D::Instance::AdaptBatchSize(const Batch& sent)
 {
     if (sent.Count() == 0) return;
     const size_t avg = sent.Size() / sent.Count() + 4;
+    if (avg < 128 + 4) return;   // short strings: a batch of the configured size already holds plenty
     size_t want = avg << 19;
     want = (want + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
     if (want > m_cfg.batch_bytes_max) want = m_cfg.batch_bytes_max;
@@ -230,7 +231,12 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
     if (!m_batch.Push(bytes, size)) {
         // batch full: map it and continue in a fresh one on the same device
         const int dev = m_slices.Current().Device();
+        const bool was_empty = m_batch.Empty();
         if (!MapCurrent()) return (m_ok = false);
+        if (was_empty && !GrowBatchesFor(dev, size)) {
+            std::cerr << "A string of " << size << " byte(s) does not fit an empty batch." << std::endl;
+            return false;
+        }
         if (!NewBatch(dev) || !m_batch.Push(bytes, size)) {
             // refuse this string only: what was added before still has a root
             // (the caller stops reading and prints it, reference Vkmr.cpp:44-55)
@@ -273,15 +279,31 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
             const int dev = slice.Device();
             const bool was_empty = m_batch.Empty();
             if (!MapCurrent()) return (m_ok = false);
-            if (!NewBatch(dev)) return (m_ok = false);
-            if (was_empty) {   // even an empty batch cannot take the next line
+            if (was_empty) {   // even an empty batch cannot take the next line: larger batches, if allowed
                 const char* nl = static_cast<const char*>(memchr(buf + pos, '\n', len - pos));
-                std::cerr << "A string of " << (nl ? (size_t)(nl - (buf + pos)) : len - pos)
-                          << " byte(s) does not fit an empty batch." << std::endl;
-                return false;
+                const size_t size = nl ? (size_t)(nl - (buf + pos)) : len - pos;
+                if (!GrowBatchesFor(dev, size)) {
+                    std::cerr << "A string of " << size << " byte(s) does not fit an empty batch." << std::endl;
+                    return false;
+                }
             }
+            if (!NewBatch(dev)) return (m_ok = false);
         }
     }
+    return true;
+}
+
+// A string that does not fit an empty batch of the current size: batches become large enough for it,
+// within batch_bytes_max (the reference's batches are 256 MiB, SHA-256vk.cpp:23, :247-248; ours start
+// smaller, so a string the reference would take must not be refused here).
+bool HipSha256D::Instance::GrowBatchesFor(int dev, size_t string_bytes)
+{
+    size_t want = (string_bytes + 4 + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
+    if (want > m_cfg.batch_bytes_max) want = m_cfg.batch_bytes_max;
+    Batches& pool = *Dev(dev).batches;
+    if (want <= pool.DataBytes() || (string_bytes + 3) / 4 * 4 > want) return false;
+    if (m_cfg.verbose) std::cout << "A string of " << string_bytes << " bytes: batches of " << (want >> 20) << " MiB from now on." << std::endl;
+    pool.Reshape(want, pool.MetaCount());
     return true;
 }
 

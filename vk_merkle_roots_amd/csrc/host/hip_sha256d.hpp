@@ -75,6 +75,7 @@ private:
     bool NewBatch(int dev);                              // m_batch <- a batch of `dev`, waiting for one to retire if need be
     bool WaitForMemory();                                // blocks on the oldest reduction / mapping; false when nothing is in flight
     void AdaptBatchSize(const Batch& sent);              // long strings: larger batches from now on
+    bool GrowBatchesFor(int dev, size_t string_bytes);   // a string larger than the current batches: grow them, if allowed
 
     HipConfig m_cfg;
     std::vector<PerDevice> m_devs;
