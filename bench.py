@@ -3,25 +3,34 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--leaves-log2 26] [--maxlen 127]
 
-One "step" = one pass of the hot path (map -> reduce -> combine) over the whole
-synthetic workload, with the packed batches already resident in HBM.  The workload
-is BASELINE.json's configs[2]: `rndm <seed> 2^26 127` (the restated glibc rand()
-generator in csrc/host/rndm_stream.cpp produces the identical strings straight into
-packed batches).  With N > 1 (launched by torch.distributed.run, one rank per GPU)
-every rank holds its own 2^26 leaves (weak scaling: slices sharded across GPUs, no
-data-path collective), reduces them to slice roots, and the roots are gathered once
-over RCCL and combined on rank 0.
+One "step" = one pass of the hot path (map -> reduce -> gather -> combine) over the whole
+synthetic workload, with the packed batches already resident in HBM.  The workload is
+BASELINE.json's configs[2]: `rndm <seed> 2^26 127` (the restated glibc rand() generator in
+csrc/host/rndm_stream.cpp produces the identical strings straight into packed batches).
 
-Prints ONE JSON line on rank 0 (see the driver contract): `value` is whole-job leaf
-hashes/s; `roofline` prices the dominant kernel against HBM (the spec'd bound) and
-carries the int32-VALU bound the path actually sits under; `cpu_baseline` is the
-reference's own CPU-serial path (oracle/_ref, built from the reference sources)
-timed on a bounded prefix of the same stream on this box's host cores.
+N > 1 is configs[3] (2^29 leaves on 8 GPUs): one process per GPU, rank r holds the 2^26 leaves
+of `rndm 42+r` as ONE slice (north star: slices shard one-per-GPU), maps and reduces them to
+one 32-byte sub-tree root, the N roots cross xGMI in ONE RCCL all-gather issued through the
+C ABI (vkmr_hip_gather_roots_async) and are combined on the GPU.  No data-path collective
+besides that; weak scaling.  The ranks are either started by torch.distributed.run (the driver's
+form) or -- `python bench.py --gpus N` without WORLD_SIZE -- by this script itself, as N child
+processes spawned before anything touches the GPU.  Fewer than N GPUs, or RCCL unusable: the
+run FAILS; it never reports a smaller N or another transport as if it were the requested one.
+
+Prints ONE JSON line on rank 0 (see the driver contract): `value` is whole-job leaf hashes/s;
+`roofline` prices the dominant kernel (map) against HBM (the spec'd bound), `roofline_reduce`
+the reduction, `valu_roofline` carries the int32-VALU bound the path actually sits under;
+`root_matches_golden` checks the timed path's root (and every rank's sub-root) against
+tests/golden/big_roots.json, which holds what the reference's own CPU path printed for these
+streams; `cpu_baseline` is that CPU path (oracle/_ref, built from the reference sources) timed
+on a bounded prefix of the same stream on this box's host cores; `long_strings` is the map
+kernel on `rndm 42 2^21 4096` (BASELINE configs[4]'s shape, one 4.3 GB batch).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -33,6 +42,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T int32 lane-ops/s
+# full-rate issue slots of the shipped code (static counts, tools/isa_count.py)
+SLOTS_BLOCK, SLOTS_DIGEST, SLOTS_NODE = 2532, 2093, 5685
 
 
 def parse():
@@ -43,18 +54,70 @@ def parse():
     p.add_argument("--leaves-log2", type=int, default=26, help="leaves per GPU (default 2^26 = configs[2])")
     p.add_argument("--maxlen", type=int, default=127, help="rndm max string length argument")
     p.add_argument("--seed", type=int, default=42)
-    p.add_argument("--slice-log2", type=int, default=23, help="digests per slice (reference: 2^23 = 256 MiB)")
+    p.add_argument("--slice-log2", type=int, default=None,
+                   help="digests per slice (default: leaves-log2, ONE slice per GPU; the reference's slice is 2^23 = 256 MiB)")
     p.add_argument("--batch-log2", type=int, default=23, help="strings per map launch (reference: <= 2^23 per batch)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-log2", type=int, default=22, help="prefix of the stream given to the CPU baseline")
+    p.add_argument("--cpu-sample-log2", type=int, default=24, help="prefix of the stream given to the CPU baseline (2^24: about 20 s)")
     p.add_argument("--levels-variant", action="store_true", help="use the one-level-per-launch reduction")
-    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsal)")
-    p.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (plumbing check)")
+    p.add_argument("--rehearse-gloo", action="store_true",
+                   help="N > 1 on a box with fewer GPUs: ranks share GPU 0 and the roots travel over gloo.  A plumbing "
+                        "rehearsal, labelled as such in the output; never a scaling result")
+    p.add_argument("--force-dist", action="store_true", help="form the process group and the RCCL communicator even with one rank")
     p.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive (pinned host -> root) measurement")
+    p.add_argument("--no-long-strings", action="store_true", help="skip the secondary long-string map measurement")
     return p.parse_args()
 
 
-def cpu_baseline(seed, maxlen, sample_log2):
+# ---- N ranks without torch.distributed.run -------------------------------------------------------
+
+def visible_gpus():
+    """GPUs this job can use, counted in a short-lived child process: the process that spawns the ranks
+    must never have touched the GPU itself."""
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    try:
+        return int(r.stdout.decode().strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start the N ranks here, one child process per GPU,
+    before any GPU call in this process; pass rank 0's JSON line through; non-zero if any rank fails."""
+    have = visible_gpus()
+    if have < a.gpus and not a.rehearse_gloo:
+        sys.stderr.write(f"[bench] --gpus {a.gpus} requested but this node has {have} GPU(s): refusing to run fewer ranks "
+                         f"or to share a GPU (use --rehearse-gloo for a plumbing rehearsal)\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:       # one rank failed: the others would wait for it until the timeout
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------
+
+def cpu_baseline(seed, maxlen, sample_log2, full_log2):
     """The reference CPU-serial path (oracle/_ref/vkmr_cpu_ref: the reference's own
     SHA-256plus/Inputs/StopWatch sources, g++ -O2) on the first 2^sample_log2 strings
     of the same rndm stream, timed by its own stopwatch line (reference Vkmr.cpp:55).
@@ -70,9 +133,14 @@ def cpu_baseline(seed, maxlen, sample_log2):
         line = [l for l in out.splitlines() if "computed root" in l]
         if line:
             ms = float(line[0].rsplit(" in ", 1)[1])
-            return {"value": n / (ms / 1e3), "unit": "leaf hashes/s", "cores": 1, "kind": "reference",
+            rate = n / (ms / 1e3)
+            return {"value": rate, "unit": "leaf hashes/s", "cores": 1, "kind": "reference",
                     "sample": sample + " (stdin parse + hash + tree, program's own stopwatch; g++ -O2)",
-                    "host_cores": os.cpu_count(), "seconds": ms / 1e3}
+                    "host_cores": os.cpu_count(), "seconds": ms / 1e3,
+                    "extrapolated_full_workload_s": (1 << full_log2) / rate,
+                    "extrapolation": f"2^{full_log2} leaves at the sample's rate (the path is linear in the leaf count: one pass over stdin, "
+                                     f"N leaf hashes, N-1 node hashes; tests/golden/big_roots.json records 232-264 s for the full stream "
+                                     f"on the build container)"}
     # port: the oracle library on a packed sample (checker timed as a baseline, never shipped)
     import vk_merkle_roots_amd as vk
     so = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -88,13 +156,16 @@ def cpu_baseline(seed, maxlen, sample_log2):
     L.oracle_root_inplace(C.c_void_p(leaves.ctypes.data), C.c_size_t(n), C.c_void_p(root.ctypes.data))
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "leaf hashes/s", "cores": 1, "kind": "port",
-            "sample": sample.replace("via stdin", "packed") + " (hash + tree only)", "host_cores": os.cpu_count(), "seconds": dt}
+            "sample": sample.replace("via stdin", "packed") + " (hash + tree only)", "host_cores": os.cpu_count(), "seconds": dt,
+            "extrapolated_full_workload_s": (1 << full_log2) / (n / dt), "extrapolation": f"2^{full_log2} leaves at the sample's rate"}
 
+
+# ---- secondary measurements (N = 1 only, outside the timed region) ---------------------------------
 
 def pipeline_rate(dev, vk, batch, nbatches, bstr, cap, nslices, slice_height, tree_height, steps=3):
     """Pipeline-level rate (SURVEY.md 8d ii): packed batches in PINNED host memory -> root, H2D copies
     on a copy stream overlapped with the map kernels on the compute stream (two HBM landing zones),
-    then the batched reduction and the combine.  PCIe-inclusive; reported beside `value`, never as it."""
+    then the reduction and the combine.  PCIe-inclusive; reported beside `value`, never as it."""
     n = batch.count
     subs = [batch.slice(b * bstr, (b + 1) * bstr) for b in range(nbatches)]
     pinned = []
@@ -132,7 +203,7 @@ def pipeline_rate(dev, vk, batch, nbatches, bstr, cap, nslices, slice_height, tr
         dev.reduce_slices_async(d_digests, nslices, cap, cap, slice_height, d_scratch, d_roots)
         src = d_roots
         if nslices > 1:
-            dev.reduce_async(d_roots, nslices, tree_height(nslices), d_top, d_final)
+            dev.combine_async(d_roots, nslices, d_top, d_final)
             src = d_final
         vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, src.ptr, 32), "d2h")
         dev.sync()
@@ -151,54 +222,111 @@ def pipeline_rate(dev, vk, batch, nbatches, bstr, cap, nslices, slice_height, tr
     return {"leaf_hashes_per_s": n / dt, "ms": dt * 1e3, "h2d_GBps": (batch.words * 4 + n * 8) / dt / 1e9, "root": final.copy()}
 
 
+def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=5):
+    """BASELINE configs[4]'s shape on the map kernel: rndm <seed> 2^21 4096 (lengths 1..4095, 1..65 blocks per
+    string) as ONE batch of about 4.3 GB -- the size a long-string batch needs to fill the chip."""
+    n = 1 << count_log2
+    b = vk.rndm_packed(seed, n, maxlen)
+    d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * n)
+    ev = [(dev.new_event(), dev.new_event()) for _ in range(launches)]
+    dev.map_async(d_data, b.words, d_meta, n, d_out)
+    dev.sync()
+    for e0, e1 in ev:
+        dev.record(e0)
+        dev.map_async(d_data, b.words, d_meta, n, d_out)
+        dev.record(e1)
+    dev.sync()
+    ms = float(np.mean([dev.elapsed_ms(e0, e1) for e0, e1 in ev]))
+    sizes = b.meta[:, 1].astype(np.int64)
+    blocks = int(((sizes + 8) // 64 + 1).sum())
+    nbytes = b.words * 4 + 40 * n
+    ops = blocks * SLOTS_BLOCK + n * SLOTS_DIGEST
+    # a checksum of the digests that the parity tests can reproduce (tests/test_gpu_fullsize.py checks every digest)
+    for buf in (d_data, d_meta, d_out):
+        buf.free()
+    return {"workload": f"rndm {seed} 2^{count_log2} {maxlen}, one batch", "strings": n, "input_bytes": int(b.words * 4), "map_ms": ms,
+            "leaf_hashes_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "kernel": "map_kernel (per-lane dwordx4 mode)", "achieved": nbytes / (ms * 1e-3) / 1e9,
+                                                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                               "algorithmic_bytes_per_launch": int(nbytes)},
+            "valu_achieved_tops": ops / (ms * 1e-3) / 1e12, "compressions_per_string": blocks / n + 1}
+
+
+def golden_big_roots(leaves_log2, maxlen):
+    path = os.path.join(ROOT, "tests", "golden", "big_roots.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("count") != (1 << leaves_log2) or rec.get("maxlen") != maxlen:
+        return None
+    return rec
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner and gloo a connection
+    # note to file descriptor 1, so everything but the result line goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the rank count must be the one asked for")
     dist = None
     tdev = None
     collective = None
     if world > 1 or a.force_dist:
+        import datetime
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        import datetime
-        collective = a.dist_backend
-        if a.dist_backend == "nccl":
-            try:
-                torch.cuda.set_device(local_rank)
-                tdev = torch.device("cuda", local_rank)
-                dist.init_process_group(backend="nccl", device_id=tdev, rank=rank, world_size=world,
-                                        timeout=datetime.timedelta(seconds=300))
-                probe = torch.ones(1, device=tdev)
-                dist.all_reduce(probe)            # first RCCL collective: fail here, not inside the timed region
-                torch.cuda.synchronize()
-            except Exception as e:                # RCCL unusable on this node: the 32-byte gather goes over gloo, and says so
-                sys.stderr.write(f"[bench] nccl/RCCL init failed on rank {rank}: {e!r}; falling back to gloo for the root gather\n")
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                tdev = None
-                collective = "gloo (RCCL init failed)"
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        if a.rehearse_gloo:
+            collective = "gloo (REHEARSAL: ranks share GPU 0, roots over host memory -- not RCCL, not a scaling result)"
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            local_rank = 0
         else:
-            dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-    if a.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+            if torch.cuda.device_count() <= local_rank:
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+            collective = "nccl"   # torch.distributed's nccl backend IS RCCL on ROCm; any failure here ends the run
+            torch.cuda.set_device(local_rank)
+            tdev = torch.device("cuda", local_rank)
+            dist.init_process_group(backend="nccl", device_id=tdev, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=300))
+            probe = torch.ones(1, device=tdev)
+            dist.all_reduce(probe)            # first RCCL collective of the control plane: fail here, not inside the timed region
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world
 
     import vk_merkle_roots_amd as vk
     from vk_merkle_roots_amd.engine import digest_hex, tree_height
 
     dev = vk.HipDevice(local_rank)
     n = 1 << a.leaves_log2
-    cap = 1 << min(a.slice_log2, a.leaves_log2)
+    slice_log2 = a.leaves_log2 if a.slice_log2 is None else min(a.slice_log2, a.leaves_log2)
+    cap = 1 << slice_log2
     bstr = 1 << min(a.batch_log2, a.leaves_log2)
     nslices = n // cap
     nbatches = n // bstr
+
+    # ---- the data-path communicator: RCCL through the C ABI, one rank per process ------------------
+    comm = None
+    if dist is not None and not a.rehearse_gloo:
+        import torch
+        uid = torch.zeros(vk._abi.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = C.create_string_buffer(vk._abi.COMM_ID_BYTES)
+            vk.check(dev.lib.vkmr_hip_comm_create_id(buf), "vkmr_hip_comm_create_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.to(tdev)
+        dist.broadcast(uid, src=0)            # the 128-byte id travels over the control plane
+        uid_bytes = bytes(uid.cpu().numpy().tobytes())
+        comm = C.c_void_p()
+        vk.check(dev.lib.vkmr_hip_comm_init_rank(local_rank, uid_bytes, world, rank, C.byref(comm)), "vkmr_hip_comm_init_rank")
 
     # ---- synthetic input: rndm stream of this rank, packed, resident in HBM -----------
     t0 = time.perf_counter()
@@ -216,59 +344,75 @@ def main():
     scratch_bytes = (dev.lib.vkmr_hip_reduce_levels_scratch_bytes(cap) if a.levels_variant
                      else dev.lib.vkmr_hip_reduce_slices_scratch_bytes(cap, nslices))
     d_scratch = dev.alloc(scratch_bytes)
-    d_top_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_scratch_bytes(max(nslices * world, 2)) + 64)
-    d_all_roots = dev.alloc(32 * nslices * world)
+    d_top_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_scratch_bytes(max(nslices, world, 2)) + 64)
+    d_sub = dev.alloc(32)                       # this rank's sub-tree root: the 32 bytes that cross xGMI
+    d_all = dev.alloc(32 * world)               # every rank's sub-tree root, in rank (= slice) order
     d_final = dev.alloc(32)
-    slice_height = min(a.slice_log2, a.leaves_log2) if (nslices * world > 1) else tree_height(n)
+    # every slice of a multi-slice tree is reduced to capacity height (reference Reductions.cpp:471); a lone slice to its own
+    slice_height = slice_log2 if (nslices * world > 1) else tree_height(n)
 
-    ev = [(dev.new_event(), dev.new_event()) for _ in range(2 * a.steps * (nbatches + 1))]
+    ev = [(dev.new_event(), dev.new_event()) for _ in range(2 * a.steps * (nbatches + 2))]
     used = []
-    host_roots = np.zeros((nslices, 8), dtype=np.uint32)
     final = np.zeros(8, dtype=np.uint32)
-    if dist is not None:
-        from vk_merkle_roots_amd.distributed import gather_roots
+    host_sub = np.zeros(8, dtype=np.uint32)
+    streams1 = (C.c_void_p * 1)(dev.stream)
+    mine1 = (C.c_void_p * 1)(d_sub.ptr)
+    all1 = (C.c_void_p * 1)(d_all.ptr)
 
-    def step(timed):
+    def timed(kind, on):
+        if not on:
+            return None
+        e0, e1 = ev[len(used)]
+        dev.record(e0)
+        used.append((kind, e0, e1))
+        return e1
+
+    def step(on):
         # MAP: one launch per batch into its place in the slice(s)
         for b in range(nbatches):
-            if timed:
-                e0, e1 = ev[len(used)]
-                dev.record(e0)
+            e1 = timed("map", on)
             d_data, words, d_meta = d_batches[b]
             dev.map_async(d_data, words, d_meta, bstr, d_digests, out_offset_digests=b * bstr)
-            if timed:
+            if e1:
                 dev.record(e1)
-                used.append(("map", e0, e1))
-        # REDUCE: every slice to its root
-        if timed:
-            e0, e1 = ev[len(used)]
-            dev.record(e0)
+        # REDUCE: this rank's leaves -> ONE sub-tree root (d_sub)
+        e1 = timed("reduce", on)
         if a.levels_variant:
             for s in range(nslices):
                 vk.check(dev.lib.vkmr_hip_reduce_levels_async(dev.index, dev.stream, d_digests.at(32 * s * cap), cap, slice_height,
-                                                              d_scratch.ptr, d_roots.at(32 * s)), "reduce_levels")
+                                                              d_scratch.ptr, (d_roots.at(32 * s) if nslices > 1 else d_sub.ptr)), "reduce_levels")
+        elif nslices == 1:
+            dev.reduce_async(d_digests, n, slice_height, d_scratch, d_sub)
         else:
             dev.reduce_slices_async(d_digests, nslices, cap, cap, slice_height, d_scratch, d_roots)
-        if timed:
+        if nslices > 1:   # several slices per GPU: their roots meet on the device first, so 32 bytes per GPU travel
+            dev.reduce_async(d_roots, nslices, tree_height(nslices), d_top_scratch, d_sub)
+        if e1:
             dev.record(e1)
-            used.append(("reduce", e0, e1))
-        # COMBINE: slice roots -> root (on device for one GPU; one RCCL gather for several)
+        # GATHER + COMBINE: N sub-tree roots -> root
         if dist is None:
-            if nslices > 1:
-                dev.reduce_async(d_roots, nslices, tree_height(nslices), d_top_scratch, d_final)
+            vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, d_sub.ptr, 32), "d2h")
+            dev.sync()
+        elif comm is not None:
+            e1 = timed("gather", on)
+            vk.check(dev.lib.vkmr_hip_gather_roots_async(comm, streams1, mine1, 1, all1), "vkmr_hip_gather_roots_async")   # ONE RCCL collective, 32 B per rank
+            if e1:
+                dev.record(e1)
+            src = d_all
+            if world > 1:
+                dev.combine_async(d_all, world, d_top_scratch, d_final)
                 src = d_final
-            else:
-                src = d_roots
             vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, src.ptr, 32), "d2h")
             dev.sync()
-        else:
-            vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, host_roots.ctypes.data, d_roots.ptr, 32 * nslices), "d2h")
+        else:   # --rehearse-gloo
+            from vk_merkle_roots_amd.distributed import gather_roots
+            vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, host_sub.ctypes.data, d_sub.ptr, 32), "d2h")
             dev.sync()
-            allr = gather_roots(host_roots, dist, rank, world, device=tdev, equal_counts=True)   # ONE RCCL gather, 32 B per slice
+            allr = gather_roots(host_sub.reshape(1, 8), dist, rank, world, device=None, equal_counts=True)
             if rank == 0:
                 allr = np.ascontiguousarray(allr)
-                vk.check(dev.lib.vkmr_hip_memcpy_h2d_async(dev.index, dev.stream, d_all_roots.ptr, allr.ctypes.data, allr.nbytes), "h2d")
-                dev.reduce_async(d_all_roots, allr.shape[0], tree_height(allr.shape[0]), d_top_scratch, d_final)
+                vk.check(dev.lib.vkmr_hip_memcpy_h2d_async(dev.index, dev.stream, d_all.ptr, allr.ctypes.data, allr.nbytes), "h2d")
+                dev.combine_async(d_all, world, d_top_scratch, d_final)
                 vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, d_final.ptr, 32), "d2h")
                 dev.sync()
 
@@ -296,33 +440,47 @@ def main():
         dt = float(t.item())
 
     # per-kernel averages from the HIP events recorded on the launch stream
-    map_ms = [dev.elapsed_ms(e0, e1) for k, e0, e1 in used if k == "map"]
-    red_ms = [dev.elapsed_ms(e0, e1) for k, e0, e1 in used if k == "reduce"]
-    map_launch_ms = float(np.mean(map_ms))
-    red_step_ms = float(np.mean(red_ms))
+    def mean_ms(kind):
+        v = [dev.elapsed_ms(e0, e1) for k, e0, e1 in used if k == kind]
+        return float(np.mean(v)) if v else None
+    map_launch_ms, red_step_ms, gather_ms = mean_ms("map"), mean_ms("reduce"), mean_ms("gather")
 
     if rank == 0:
         total_leaves = n * world
         ms_per_step = dt / a.steps * 1e3
         value = total_leaves * a.steps / dt
+        root_hex = digest_hex(final)
+        sub_roots = ([digest_hex(r) for r in dev.download(d_all, 32 * world).reshape(-1, 8)] if comm is not None or a.rehearse_gloo
+                     else [digest_hex(dev.download(d_sub, 32))])
+        # the timed path's own result against what the reference CPU path printed for these streams
+        golden = golden_big_roots(a.leaves_log2, a.maxlen) if a.seed == 42 else None
+        root_ok = subs_ok = None
+        if golden:
+            want = golden.get("combined", {}).get(str(world))
+            root_ok = (root_hex == want) if want else None
+            have = [golden["sub_roots"].get(str(a.seed + r), {}).get("root") for r in range(world)]
+            subs_ok = (sub_roots == have) if all(have) else None
         # algorithmic bytes of one map launch: packed words + 8 B metadata read, 32 B digest written
         map_bytes = (batch.words * 4 + 8 * n + 32 * n) / nbatches
         achieved = map_bytes / (map_launch_ms * 1e-3) / 1e9
-        # int32 VALU work in full-rate issue slots (static counts of the shipped code, tools/isa_count.py):
-        # data block 2202 (compression) + ~330 (fetch, byte swap, padding masks), digest hash 2093, tree node 5685
+        # the reduction reads every digest once at tree level 0 (32 B per leaf); the levels above add 2/32 + 2/1024 + ... of that
+        red_bytes = 32.0 * n * (1 + 2 / 32 + 2 / 1024)
+        red_achieved = red_bytes / (red_step_ms * 1e-3) / 1e9
         sizes = batch.meta[:, 1].astype(np.int64)
         blocks = int(((sizes + 8) // 64 + 1).sum())
-        map_ops = blocks * 2532 + n * 2093
-        red_ops = (n - nslices) * 5685
-        # HBM bytes per map launch from the PMC passes of the SAME launch shape (profiles/pmc_latest.json,
+        map_ops = blocks * SLOTS_BLOCK + n * SLOTS_DIGEST
+        red_ops = (n - 1) * SLOTS_NODE
+        # HBM bytes per launch from the PMC passes of the SAME launch shape (profiles/pmc_latest.json,
         # written by tools/pmc_profile.sh + tools/pmc_to_json.py on the GPU box); null when none matches
-        traffic = None
+        traffic = red_traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("strings_per_map_launch") == bstr and rec.get("maxlen") == a.maxlen and not os.environ.get("VKMR_MAP_VARIANT"):
                     traffic = rec.get("map_kernel_hbm_bytes_per_launch")
+                    if rec.get("slice_log2") == slice_log2:
+                        red_traffic = rec.get("reduce_hbm_bytes_per_step")
             except Exception:
                 traffic = None
         out = {
@@ -331,32 +489,56 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"rndm {a.seed}+rank 2^{a.leaves_log2} {a.maxlen} per GPU (BASELINE configs[2])",
-                       "leaves_per_gpu": n, "slices_per_gpu": nslices, "slice_capacity": cap, "map_launches_per_step": nbatches,
-                       "input_bytes_per_gpu": int(input_bytes), "parallelism": f"slices sharded over {world} GPU(s)", "collective": (collective if dist is not None else None),
+            "config": {"workload": f"rndm {a.seed}+rank 2^{a.leaves_log2} {a.maxlen} per GPU (BASELINE configs[{2 if world == 1 else 3}]"
+                                   f"{'' if world in (1, 8) else ' shape at ' + str(world) + ' GPUs'})",
+                       "leaves_per_gpu": n, "leaves_total": total_leaves, "slices_per_gpu": nslices, "slice_capacity": cap,
+                       "map_launches_per_step": nbatches, "input_bytes_per_gpu": int(input_bytes),
+                       "parallelism": f"one process per GPU, slices sharded over {world} GPU(s), no data-path collective but the root gather",
+                       "collective": collective, "ranks": world,
+                       "gather": (None if dist is None else ("vkmr_hip_gather_roots_async: 1 ncclAllGather of 32 B per rank (C ABI, librccl)" if comm is not None
+                                                             else "torch.distributed gather over gloo (rehearsal)")),
+                       "bytes_gathered_per_step": (32 * world if dist is not None else 0),
                        "kernels": dev.lib.vkmr_hip_kernel_info().decode(), "reduce_variant": "levels" if a.levels_variant else "wave"},
-            "root": digest_hex(final),
+            "root": root_hex,
+            "sub_roots": sub_roots,
+            "root_matches_golden": root_ok,
+            "sub_roots_match_golden": subs_ok,
+            "golden": "tests/golden/big_roots.json (reference CPU path on the same rndm streams)" if golden else None,
             "merkle_root_wall_ms": ms_per_step,
             "roofline": {"bound": "hbm", "kernel": "map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "launch_ms": map_launch_ms, "algorithmic_bytes_per_launch": map_bytes},
-            "valu_roofline": {"bound": "int32-valu issue slots (v_alignbit/v_add3/v_perm count 2)", "sustained_tops_measured": 64.0, "map_ms_per_step": map_launch_ms * nbatches, "reduce_ms_per_step": red_step_ms,
+            "roofline_reduce": {"bound": "hbm", "kernel": "reduce_pass_kernel + reduce_collapse_kernel + reduce_tail_kernel (one slice reduction)",
+                                "achieved": red_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": red_achieved / HBM_PEAK_GBPS,
+                                "traffic": red_traffic, "step_ms": red_step_ms, "algorithmic_bytes_per_step": red_bytes},
+            "valu_roofline": {"bound": "int32-valu issue slots (v_alignbit/v_add3/v_perm count 2)", "sustained_tops_measured": 64.0,
+                              "map_ms_per_step": map_launch_ms * nbatches, "reduce_ms_per_step": red_step_ms,
                               "map_achieved_tops": map_ops / (map_launch_ms * nbatches * 1e-3) / 1e12,
                               "reduce_achieved_tops": red_ops / (red_step_ms * 1e-3) / 1e12,
                               "peak_tops": VALU_PEAK_TOPS,
                               "map_frac": map_ops / (map_launch_ms * nbatches * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                               "reduce_frac": red_ops / (red_step_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS},
+            "gather_ms": gather_ms,
             "setup": {"generate_s": t_gen, "h2d_pageable_s": t_h2d},
         }
         if world == 1 and not a.no_pipeline and not a.levels_variant:
             pl = pipeline_rate(dev, vk, batch, nbatches, bstr, cap, nslices, slice_height, tree_height)
             out["pipeline_pcie_inclusive"] = {"leaf_hashes_per_s": pl["leaf_hashes_per_s"], "ms": pl["ms"], "h2d_GBps": pl["h2d_GBps"],
-                                              "root_matches": digest_hex(pl["root"]) == digest_hex(final),
+                                              "root_matches": digest_hex(pl["root"]) == root_hex,
                                               "what": "pinned host batches -> async H2D overlapped with map -> reduce -> root"}
+        if world == 1 and not a.no_long_strings:
+            for b_ in d_batches:
+                b_[0].free()
+                b_[2].free()
+            d_digests.free()
+            out["long_strings"] = long_strings_rate(dev, vk, a.seed)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.seed, a.maxlen, min(a.cpu_sample_log2, a.leaves_log2))
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(a.seed, a.maxlen, min(a.cpu_sample_log2, a.leaves_log2), a.leaves_log2)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        dev.lib.vkmr_hip_comm_destroy(comm)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

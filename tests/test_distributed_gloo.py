@@ -73,6 +73,26 @@ def test_two_ranks_sharded_slices(native, oracle, tmp_path, n, cap_log2):
     assert open(out).read() == want
 
 
+@pytest.mark.parametrize("n,cap_log2", [(8 * 512, 9), (7 * 512 + 100, 9), (7 * 1024 + 1, 10)])
+def test_eight_ranks_one_slice_each_ragged_last(native, oracle, tmp_path, n, cap_log2):
+    """BASELINE configs[3]'s shape in small: eight ranks, ONE slice per rank, the last rank's slice short (it is
+    still reduced to capacity height, reference Reductions.cpp:471), eight roots in one gather, combine on rank 0."""
+    import torch.multiprocessing as mp
+    import vk_merkle_roots_amd as vk
+    out = str(tmp_path / "root.txt")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, 91, n, cap_log2, out)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    b = vk.rndm_packed(91, n, 127)
+    want = oracle.hex(oracle.root(oracle.leaves_packed(b.data, b.meta)))
+    assert open(out).read() == want
+
+
 def test_shard_plan_covers_everything():
     from vk_merkle_roots_amd.distributed import shard_slices
     for total in range(0, 40):

@@ -106,3 +106,28 @@ def test_config5_full_2p24_x_4k(gpu, oracle):
     gpu.reduce_slices_async(d_digests, 2, 1 << 23, 1 << 23, 23, d_scratch, d_roots)
     gpu.reduce_async(d_roots, 2, 1, d_top, d_final)
     assert digest_hex(gpu.download(d_final, 32)) == oracle.hex(oracle.root(want, threads=64))
+
+
+def test_one_string_of_512_mib_plus_5_bytes(gpu, oracle):
+    """The 64-bit bit length: a string of 2^29 + 5 bytes has bit length 2^32 + 40, so the high length word of the
+    padding (size >> 29) is 1 -- zero in every other test.  The reference's own shader is wrong here
+    (MB_SIZE_TOP, src/common/SHA-256defs.h:30, masks instead of shifting), so the CPU path (the oracle) is the
+    authority.  One lane hashes 8.4 M blocks in sequence -- SHA-256 is a chain -- so this one launch takes
+    the better part of a minute; two short strings ride along in the same batch."""
+    import vk_merkle_roots_amd as vk
+    big = (1 << 29) + 5
+    rng = np.random.default_rng(2929)
+    words = (big + 3) // 4
+    data = rng.integers(0, 2**32, size=words + 32, dtype=np.uint32)
+    raw = data.view(np.uint8)
+    raw[big: 4 * words] = 0
+    small = [(words, 3), (words + 1, 100)]
+    meta = np.array([(0, big)] + small, dtype=np.uint32)
+    batch = vk.PackedBatch(data, meta, words + 32, big + 103)
+    got = gpu.leaf_digests(batch)
+    want = oracle.leaves_packed(data, meta, threads=3)
+    assert (got == want).all()
+    # and the oracle itself against hashlib on this one input (the golden vectors stop at 4 KiB)
+    import hashlib
+    h = hashlib.sha256(hashlib.sha256(raw[:big].tobytes()).digest()).digest()
+    assert oracle.hex(want[0]) == h.hex()

@@ -75,3 +75,21 @@ def test_rndm_stream_batches_equal_one_shot(native):
         ref = whole.slice(lo, lo + p.count)
         assert (p.meta == ref.meta).all() and (p.data == ref.data).all()
         lo += p.count
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` must never report a smaller N: with fewer than N GPUs (none here, one on the GPU box
+    for N = 2) it exits non-zero before starting any rank and prints no result line."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "9", "--steps", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert r.returncode != 0
+    assert r.stdout.strip() == b""
+    assert b"refusing to run fewer ranks" in r.stderr
+    # under a launcher the rank count must be the requested one too
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == b""

@@ -4,7 +4,7 @@
 # Usage (from the repo root on the box):  bash tools/pmc_profile.sh <tag> [bench args...]
 set -o pipefail
 TAG=${1:-run}; shift
-ARGS=${@:---leaves-log2 26 --steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---leaves-log2 26 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-long-strings}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -17,5 +17,6 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run fetch FETCH_SIZE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+run rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum     # request-size split: every read request of gfx950 is 128 B (32B = 0)
 python3 $REPO/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -60,8 +60,14 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
                 uint32_t l[8], r[8];
                 if (k == 0) {
                     if (2 * j < ck) {
+                        // both nodes in one go: the four 16-byte loads issue back to back, so the 128-byte
+                        // line two lanes share is requested once.  (A conditional second load is compiled as
+                        // load - wait - branch - load; by then the line has left L1 and often L2:
+                        // 1.5x the algorithmic HBM reads, profiles/r02_reduce_fetch.txt.)  An odd count
+                        // pairs the last node with itself: it is simply read twice.
+                        const uint64_t jb = (2 * j + 1 < ck) ? 2 * j + 1 : 2 * j;
                         const Node a = vkmr_dev::load_node(in + 2 * j);
-                        const Node b = (2 * j + 1 < ck) ? vkmr_dev::load_node(in + 2 * j + 1) : a;
+                        const Node b = vkmr_dev::load_node(in + jb);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { l[i] = a.w[i]; r[i] = b.w[i]; }
                     }
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restric
     }
     if (2 * tid < n_in) {
         const Node a = vkmr_dev::load_node(in + 2 * tid);
-        const Node b = (2 * tid + 1 < n_in) ? vkmr_dev::load_node(in + 2 * tid + 1) : a;
+        const Node b = vkmr_dev::load_node(in + ((2 * tid + 1 < n_in) ? 2 * tid + 1 : 2 * tid));
         vkmr_dev::hash_pair(a.w, b.w, X);
     }
     done = 1;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(64) void reduce_collapse_kernel(const Node* __restr
     uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (2 * j < n_in) {
         const Node a = vkmr_dev::load_node(in + 2 * j);
-        const Node b = (2 * j + 1 < n_in) ? vkmr_dev::load_node(in + 2 * j + 1) : a;
+        const Node b = vkmr_dev::load_node(in + ((2 * j + 1 < n_in) ? 2 * j + 1 : 2 * j));
         vkmr_dev::hash_pair(a.w, b.w, X);
     }
     uint32_t done = 1;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256) void reduce_level_kernel(const Node* __restric
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * p >= n_in) return;
     const Node a = vkmr_dev::load_node(in + 2 * p);
-    const Node b = (2 * p + 1 < n_in) ? vkmr_dev::load_node(in + 2 * p + 1) : a;
+    const Node b = vkmr_dev::load_node(in + ((2 * p + 1 < n_in) ? 2 * p + 1 : 2 * p));
     uint32_t o[8];
     vkmr_dev::hash_pair(a.w, b.w, o);
     vkmr_dev::store_node(out + p, o);
