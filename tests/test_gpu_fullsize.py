@@ -35,6 +35,12 @@ def test_config3_2p26_leaves(gpu, oracle):
     del got
     want_root = oracle.hex(oracle.root(want_leaves, threads=64))
     del want_leaves
+    # ... and what the reference's own CPU path printed for this stream (tests/golden/big_roots.json)
+    import json
+    import os
+    from conftest import ROOT
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "big_roots.json")))
+    assert big["count"] == n and want_root == big["sub_roots"]["42"]["root"]
 
     # (2) 8 slices of 2^23 reduced by one batched call + on-device combine
     d_scratch = gpu.alloc(gpu.lib.vkmr_hip_reduce_slices_scratch_bytes(1 << 23, 8))

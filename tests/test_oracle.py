@@ -146,3 +146,19 @@ def test_reference_driver_matches_golden(golden):
     s = golden["streams"]["L2_empty_lines"]
     out = subprocess.run([exe], input=bytes.fromhex(s["stream_hex"]), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
     assert f"CPU: computed root (of {s['items']} item(s), {s['bytes']} byte(s)) => {s['root']} in " in out
+
+
+def test_big_roots_fixture_is_consistent(oracle):
+    """tests/golden/big_roots.json (the reference CPU path on rndm 42..49 2^26 127): combined[N] is the duplicate-last
+    tree over the first N sub-roots in order (reference Reductions.cpp:703-712), N = 1 the root itself."""
+    import json
+    import os
+    from conftest import ROOT
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "big_roots.json")))
+    assert big["count"] == 1 << 26 and big["maxlen"] == 127
+    subs = [big["sub_roots"][str(42 + r)] for r in range(8)]
+    assert all(s["items"] == 1 << 26 for s in subs) and len({s["root"] for s in subs}) == 8
+    words = np.array([np.frombuffer(bytes.fromhex(s["root"]), dtype=">u4").astype(np.uint32) for s in subs], dtype=np.uint32)
+    for n in range(1, 9):
+        want = subs[0]["root"] if n == 1 else oracle.hex(oracle.root(words[:n]))
+        assert big["combined"][str(n)] == want, n

@@ -5,7 +5,7 @@ tallies the 128-byte requests of gfx950 as 64 bytes -> x2; WRITE_SIZE in KiB is 
 reduction's pair loads too: tools/fetch_calibrate.hip reads 1 GiB in that pattern and FETCH_SIZE x 2 returns
 1.074e9 bytes, every TCC_EA0_RDREQ being a 128-byte request (profiles/r02_fetch_calibration.txt).
 
-    python3 tools/pmc_to_json.py <pmc dir> <out.json> [--batch-log2 23] [--maxlen 127] [--slice-log2 26] [--launches-per-step 8]
+    python3 tools/pmc_to_json.py <pmc dir> <out.json> [--batch-log2 26] [--maxlen 127] [--slice-log2 26] [--launches-per-step 1]
 """
 import argparse
 import collections
@@ -19,10 +19,10 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("root")
     p.add_argument("out")
-    p.add_argument("--batch-log2", type=int, default=23)
+    p.add_argument("--batch-log2", type=int, default=26)
     p.add_argument("--maxlen", type=int, default=127)
     p.add_argument("--slice-log2", type=int, default=26)
-    p.add_argument("--launches-per-step", type=int, default=8)
+    p.add_argument("--launches-per-step", type=int, default=1)
     a = p.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), recursive=True):
