@@ -5,7 +5,7 @@ from conftest import Oracle
 o = Oracle(); gpu = vk.HipDevice(0)
 rng = np.random.default_rng(int(time.time()))
 t0 = time.time(); cases = 0
-while time.time() - t0 < 90:
+while time.time() - t0 < (float(sys.argv[1]) if len(sys.argv) > 1 else 90):
     # random stream -> root via random slicing, both map modes via batched/unbatched engine paths
     n = int(rng.choice([rng.integers(1, 2000), rng.integers(1, 200000)]))
     maxlen = int(rng.choice([2, 20, 65, 127, 300, 2000]))

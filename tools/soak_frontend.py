@@ -1,0 +1,44 @@
+"""Random streams through the C++ front end (`vkmr hip:0`, and `vkmr hip:all` over an aliased GPU) with random
+pipeline shapes -- slice size, batch size, mappings in flight, slice budget -- against the oracle.  GPU box only.
+    python3 tools/soak_frontend.py [seconds]"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import Oracle, build_virt_devices  # noqa: E402
+
+o = Oracle()
+vkmr = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "vkmr")
+rndm = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "rndm")
+virt = build_virt_devices()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+rng = np.random.default_rng(int(time.time()))
+t0 = time.time()
+cases = 0
+while time.time() - t0 < budget:
+    n = int(rng.choice([rng.integers(1, 3000), rng.integers(1, 300000)]))
+    maxlen = int(rng.choice([2, 20, 65, 127, 300, 3000]))
+    seed = int(rng.integers(1, 2**31))
+    stream = subprocess.run([rndm, str(seed), str(n), str(maxlen)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    want, cnt, nb = o.root_of_stream(stream)
+    env = dict(os.environ, VKMR_SLICE_LOG2=str(int(rng.integers(1, 19))), VKMR_BATCH_BYTES=str(int(rng.integers(4096, 1 << 22))),
+               VKMR_MAX_INFLIGHT=str(int(rng.integers(1, 6))), VKMR_PACK_THREADS=str(int(rng.integers(1, 9))))
+    if rng.integers(0, 2):
+        env["VKMR_SLICE_BUDGET"] = str(int(rng.integers(1, 4)))
+    backend = "hip:0"
+    if rng.integers(0, 3) == 0:
+        env.update(LD_PRELOAD=virt, VKMR_TEST_VIRTUAL_DEVICES=str(int(rng.integers(2, 9))))
+        backend = "hip:all"
+    r = subprocess.run([vkmr, backend], input=stream, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    line = [l for l in r.stdout.decode().splitlines() if "computed root" in l]
+    shape = {k: v for k, v in env.items() if k.startswith("VKMR_")}
+    assert r.returncode == 0 and line, (seed, n, maxlen, backend, shape, r.stderr[-300:])
+    assert f"(of {cnt} item(s), {nb} byte(s)) => {want} in" in line[-1], (seed, n, maxlen, backend, shape, line[-1])
+    cases += 1
+print("front-end soak ok:", cases, "random streams and pipeline shapes, all roots equal the oracle")

@@ -1,12 +1,15 @@
-"""Multi-GPU sharding of the Merkle tree: one process per GPU, slices sharded across
-ranks, one gather of the slice roots, combine on rank 0.
+"""Sharding plan of the Merkle tree over ranks, and the HOST-SIDE gather used where RCCL cannot
+run: the world-2 / world-8 gloo tests on CPU and `bench.py --rehearse-gloo`.
+
+On GPUs the roots travel through the C ABI instead (vkmr_hip_gather_roots_async: one RCCL
+all-gather over xGMI, include/vkmr_hip.h); this module is the CPU-testable twin of that step
+with the same sharding and ordering rules.
 
 The reference drives a single device and combines slice roots on the host
 (src/vkmr/Reductions.cpp:703-712); slices are independent sub-trees by design
 (README.md:94-96), so they shard with no data-path collective.  The only exchange is
 32 bytes per slice: `gather_roots` moves them to rank 0 with ONE collective
-(`torch.distributed` gather: RCCL over xGMI with the "nccl" backend, gloo in CPU tests)
-in global slice order, which is what the combine needs.
+(a `torch.distributed` gather) in global slice order, which is what the combine needs.
 
 Layout: the stream's slices are numbered 0..S-1; rank r owns the contiguous block
 [r*S/W, (r+1)*S/W) ("slices shard one-per-GPU" when S == W).  Every slice but the
