@@ -1,0 +1,163 @@
+"""The host logic of the GPU backend on a CPU-only machine: the UNMODIFIED stream processor, pools, mappings,
+reductions and the several-device combine (csrc/host/*.cpp) built with AddressSanitizer + UBSan and linked
+against a test double of the C ABI (tests/c/fake_vkmr_hip.cpp: host memory, asynchronous-looking events, hashing
+by the product's own "CPU" functions, optional HBM cap and injected device failures).  What the GPU suite cannot
+provoke on demand -- real allocation failures, failing events, failing dispatches -- is checked here: the root is
+the golden one, or there is no root, never a wrong one.  The double is test infrastructure, not a fallback: the
+product never loads it."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc", "host")
+CSRC = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc")
+OUT = os.path.join(ROOT, "tests", "_build", "fake")
+LINE = re.compile(r"^(?P<name>\S+): computed root \(of (?P<items>\d+) item\(s\), (?P<bytes>\d+) byte\(s\)\) => (?P<root>[0-9a-f]*) in [0-9.e+-]+$")
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def _newer(target, sources):
+    return os.path.exists(target) and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in sources)
+
+
+@pytest.fixture(scope="session")
+def fake_vkmr(native):
+    """(path of the sanitized vkmr linked against the fake ABI, base environment)."""
+    os.makedirs(OUT, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", CSRC]
+    lib = os.path.join(OUT, "libvkmr_hip.so")
+    lib_src = [os.path.join(ROOT, "tests", "c", "fake_vkmr_hip.cpp"), os.path.join(HOST, "cpu_sha256d.cpp")]
+    hdrs = [os.path.join(ROOT, "include", "vkmr_hip.h"), os.path.join(CSRC, "reduce_plan.hpp")]
+    if not _newer(lib, lib_src + hdrs):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-shared", "-fPIC"] + SAN + inc + lib_src + ["-o", lib])
+    exe = os.path.join(OUT, "vkmr_asan")
+    files = ["vkmr_main.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "inputs.cpp", "batches.cpp", "slices.cpp", "mappings.cpp", "reductions.cpp",
+             "stream_pack.cpp"]
+    srcs = [os.path.join(HOST, f) for f in files]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + hdrs + [lib]
+    if not _newer(exe, deps):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-pthread"] + SAN + inc + srcs + ["-o", exe, "-L", OUT, "-lvkmr_hip", "-Wl,-rpath," + OUT])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VKMR_") and k != "LD_PRELOAD"}
+    env.update(LD_LIBRARY_PATH=OUT, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    return exe, env
+
+
+def run(fake_vkmr, backend, stream, **knobs):
+    exe, env = fake_vkmr
+    env = dict(env, **{k: str(v) for k, v in knobs.items()})
+    r = subprocess.run([exe, backend], input=stream, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr and b"LeakSanitizer" not in r.stderr, r.stderr[-3000:].decode()
+    out = r.stdout.decode().splitlines()
+    res = [m for m in (LINE.match(l) for l in out) if m]
+    return r, out, (res[-1].groupdict() if res else None)
+
+
+def stream_of(native, s):
+    tool = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    if "stream_hex" in s:
+        return bytes.fromhex(s["stream_hex"])
+    return subprocess.run([tool] + s["generator"].split()[1:], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+
+
+SHAPES = [
+    {},
+    {"VKMR_SLICE_LOG2": 10, "VKMR_BATCH_BYTES": 65536, "VKMR_MAX_INFLIGHT": 2},
+    {"VKMR_SLICE_LOG2": 12, "VKMR_BATCH_BYTES": 20000, "VKMR_MAX_INFLIGHT": 1, "VKMR_FAKE_EVENT_POLLS": 7},
+    {"VKMR_SLICE_LOG2": 6, "VKMR_BATCH_BYTES": 8192, "VKMR_SLICE_BUDGET": 1, "VKMR_FAKE_EVENT_POLLS": 0},
+    {"VKMR_SLICE_LOG2": 16, "VKMR_BATCH_MB": 1, "VKMR_VERBOSE": 1, "VKMR_PACK_THREADS": 5},
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_golden_streams_through_the_host_pipeline(fake_vkmr, native, golden, shape):
+    for name in ("G2_rndm_1712489279_1024_127", "G6_rndm_7_1000_300", "G4_rndm_42_4096_4096", "L2_empty_lines", "L3_no_trailing_newline", "L7_three"):
+        s = golden["streams"][name]
+        r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), **shape)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert m and (m["name"], int(m["items"]), int(m["bytes"]), m["root"]) == ("hip:0", s["items"], s["bytes"], s["root"]), (name, shape)
+
+
+@pytest.mark.parametrize("ndev,shape", [(2, {"VKMR_SLICE_LOG2": 7}), (3, {"VKMR_SLICE_LOG2": 5, "VKMR_BATCH_BYTES": 8192}),
+                                        (8, {"VKMR_SLICE_LOG2": 7}), (5, {"VKMR_SLICE_LOG2": 9}), (4, {"VKMR_SLICE_LOG2": 3, "VKMR_SLICE_BUDGET": 1})])
+def test_hip_all_over_several_devices(fake_vkmr, native, golden, ndev, shape):
+    """Slices dealt round-robin, one root array per device, ONE gather, slice order, combine on the first device --
+    including fewer slices than devices and more than 4096 / ndev slices per device is not needed to see the order."""
+    for name in ("G2_rndm_1712489279_1024_127", "G6_rndm_7_1000_300", "L7_three"):
+        s = golden["streams"][name]
+        r, out, m = run(fake_vkmr, "hip:all", stream_of(native, s), VKMR_FAKE_DEVICES=ndev, **shape)
+        assert r.returncode == 0 and out[0] == "Initializing for: hip:all", r.stderr[-500:]
+        assert m and (int(m["items"]), m["root"]) == (s["items"], s["root"]), (name, ndev, shape)
+
+
+def test_root_array_grows_past_its_first_capacity(fake_vkmr, native, oracle):
+    """More than 4096 slices on one device: the per-device root array is re-allocated and the roots copied over."""
+    tool = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    stream = subprocess.run([tool, "5", "20000", "20"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    want, cnt, nb = oracle.root_of_stream(stream)
+    r, out, m = run(fake_vkmr, "hip:0", stream, VKMR_SLICE_LOG2=2)          # 5000 slices of 4
+    assert m and (m["root"], int(m["items"])) == (want, cnt), r.stderr[-300:]
+    r, out, m = run(fake_vkmr, "hip:all", stream, VKMR_SLICE_LOG2=1, VKMR_FAKE_DEVICES=2)   # 10000 slices over 2 devices
+    assert m and m["root"] == want
+
+
+def test_real_allocation_failures_wait_instead_of_halting(fake_vkmr, native, golden):
+    """HBM that holds two slices plus the batches: device_alloc returns VKMR_ERR_OOM, the stream processor blocks on the
+    oldest reduction / mapping and re-uses what comes back (reference README.md:113; it halts, SHA-256vk.cpp:396-399)."""
+    s = golden["streams"]["G6_rndm_7_1000_300"]
+    stream = stream_of(native, s)
+    # slices of 2^5 cells = 1 KiB; batches of 16 KiB data + 4 KiB meta per landing zone; scratch and root arrays are small
+    # the root array (4096 x 32 B) and one scratch set are reserved when the backend starts: 131 KiB
+    for hbm, budget in ((400000, 64), (260000, 64), (160000, 8)):
+        r, out, m = run(fake_vkmr, "hip:0", stream, VKMR_SLICE_LOG2=5, VKMR_BATCH_BYTES=16384, VKMR_BATCH_MAX_MB=0, VKMR_MAX_INFLIGHT=4,
+                        VKMR_SLICE_BUDGET=budget, VKMR_FAKE_HBM_BYTES=hbm)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert m and (int(m["items"]), m["root"]) == (s["items"], s["root"]), (hbm, r.stderr[-300:])
+
+
+def test_no_room_for_the_reduction_reserve_is_reported_at_start(fake_vkmr):
+    r, out, m = run(fake_vkmr, "hip:0", b"a\nb\n", VKMR_SLICE_LOG2=5, VKMR_FAKE_HBM_BYTES=100000)
+    assert r.returncode == 0 and m is None
+    assert b"Failed to prepare reductions" in r.stderr
+
+
+def test_allocation_failure_with_nothing_in_flight_is_reported(fake_vkmr):
+    """No room for even one slice: Add() refuses, nothing is printed, exit code 0 (reference Vkmr.cpp:44-52)."""
+    r, out, m = run(fake_vkmr, "hip:0", b"a\nb\n", VKMR_SLICE_LOG2=20, VKMR_FAKE_HBM_BYTES=30 << 20)   # the reserve (25 MB of scratch) fits, a 32 MiB slice does not
+    assert r.returncode == 0 and m is None
+    assert b"Failed to allocate slice" in r.stderr
+
+
+@pytest.mark.parametrize("which", range(1, 40, 3))
+def test_a_failing_event_never_yields_a_wrong_root(fake_vkmr, native, golden, which):
+    """a mapping or reduction whose event reports a device error must not contribute a zero-filled or
+    missing root.  Whatever event fails, the printed root is the golden one (the failure hit nothing that mattered,
+    e.g. a timing event) or empty -- never anything else."""
+    s = golden["streams"]["G6_rndm_7_1000_300"]
+    r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), VKMR_SLICE_LOG2=6, VKMR_BATCH_BYTES=16384, VKMR_FAKE_FAIL_EVENT=which,
+                    VKMR_FAKE_EVENT_POLLS=1)
+    assert r.returncode == 0
+    assert m is None or m["root"] in ("", s["root"]), (which, m)
+    if m is not None and m["root"] == "":
+        assert b"failed" in r.stderr or b"Reduced" in r.stderr
+
+
+@pytest.mark.parametrize("which", [1, 2, 7, 16])
+def test_a_failing_reduce_dispatch_yields_no_root(fake_vkmr, native, golden, which):
+    """The last slice's Reduce failing used to leave the roots of slices 1..n-1 to be combined and printed."""
+    s = golden["streams"]["G6_rndm_7_1000_300"]        # 1000 strings, slices of 64: 16 reductions
+    r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), VKMR_SLICE_LOG2=6, VKMR_FAKE_FAIL_REDUCE=which)
+    assert r.returncode == 0
+    assert m is None or m["root"] == "", (which, m)
+    assert b"Failed to dispatch a reduction" in r.stderr
+
+
+def test_hip_all_combine_failure_is_loud(fake_vkmr, native, golden):
+    s = golden["streams"]["G2_rndm_1712489279_1024_127"]
+    # 16 slices over 4 devices; the 17th reduce call is the combine on device 0
+    r, out, m = run(fake_vkmr, "hip:all", stream_of(native, s), VKMR_SLICE_LOG2=6, VKMR_FAKE_DEVICES=4, VKMR_FAKE_FAIL_REDUCE=17)
+    assert m is None or m["root"] == ""
+    assert b"Failed to combine the slice roots" in r.stderr

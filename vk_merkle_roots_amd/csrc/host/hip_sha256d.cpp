@@ -98,6 +98,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
     m_mappings = Mappings::New(cfg.verbose);
     m_reductions = Reductions::New(devices, (size_t)1 << cfg.slice_log2, cfg.verbose);
     if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
+    if (!m_reductions->Ok()) m_ok = false;   // reported by Reductions::New
 }
 
 HipSha256D::Instance::~Instance()
@@ -217,6 +218,7 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
     // (reference SHA-256vk.cpp:318-335)
     m_reductions->Update();
     if (m_mappings->InFlight()) Account(m_mappings->Update());
+    if (!m_ok || !m_reductions->Ok()) return (m_ok = false);   // a mapping or reduction failed on the device: stop reading
 
     // A failed allocation refuses this string but keeps what was added: the caller stops
     // reading and Root() still covers the earlier strings (reference: Add returns false,
@@ -257,6 +259,7 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
     while (pos < len) {
         m_reductions->Update();
         if (m_mappings->InFlight()) Account(m_mappings->Update());
+        if (!m_ok || !m_reductions->Ok()) return (m_ok = false);   // a mapping or reduction failed on the device: stop reading
         if (!m_slices.Current()) {
             if (!StartSliceAndBatch()) return false;
         } else if (m_slices.Current().Available() == 0) {

@@ -64,6 +64,7 @@ public:
     virtual bool WaitOne() = 0;
     virtual size_t InFlight() const = 0;
     virtual size_t Allocations() const = 0;   // scratch buffers allocated so far (pool bookkeeping, for the log)
+    virtual bool Ok() const = 0;              // false once a reduction could not be prepared, dispatched or completed
     // Waits for every reduction, combines the slice roots in slice order and returns
     // the hex root ("" on failure or when nothing was reduced).
     virtual ISha256D::out_type WaitFor() = 0;

@@ -45,6 +45,20 @@ public:
             pd.dev = d;
             m_devs.push_back(pd);
         }
+        // What every device needs for its first reduction is taken now, before slices and batches fill HBM:
+        // the root array and one scratch + event set.  Later reductions re-use that set (or wait for it), so
+        // a reduction can always be dispatched, however full the device is by then.
+        for (size_t di = 0; di < m_devs.size(); ++di) {
+            Resources r;
+            HipResult st = EnsureRoots(di, 0);
+            if (st == VKMR_OK) st = NewResources(m_devs[di].dev, &r);
+            if (st != VKMR_OK) {
+                std::cerr << "Failed to prepare reductions on device " << m_devs[di].dev << ": " << vkmr_hip_last_error() << std::endl;
+                m_failed = true;
+                break;
+            }
+            m_devs[di].spare.push_back(r);
+        }
     }
 
     ~ReductionsImpl() override
@@ -84,6 +98,7 @@ public:
 
     size_t InFlight() const override { return m_inflight.size(); }
     size_t Allocations() const override { return m_allocations; }
+    bool Ok() const override { return !m_failed; }
 
     ISha256D::out_type WaitFor() override
     {
@@ -124,18 +139,36 @@ private:
                 d.spare.pop_back();
                 return VKMR_OK;
             }
+            // a reduction of this device in flight will hand its set back: prefer that to another allocation
+            // once a few sets exist (they are per-reduction, and reductions of one device share a stream anyway)
+            const size_t mine = (size_t)std::count_if(m_inflight.begin(), m_inflight.end(), [&](const Reduction& r) { return r.device_index == di; });
+            if (mine >= 4) {
+                WaitOne();
+                continue;
+            }
             Resources r;
-            HipResult st = vkmr_hip_device_alloc(d.dev, m_scratch_bytes, &r.scratch);
-            if (st == VKMR_OK) st = vkmr_hip_event_create(d.dev, &r.begin);
-            if (st == VKMR_OK) st = vkmr_hip_event_create(d.dev, &r.done);
+            const HipResult st = NewResources(d.dev, &r);
             if (st == VKMR_OK) {
                 *out = r;
-                ++m_allocations;
                 return VKMR_OK;
             }
-            FreeResources(d.dev, r);
-            if (st != VKMR_ERR_OOM || !WaitOne()) return st;
+            if (st != VKMR_ERR_OOM || !WaitOne()) return st;   // with a set reserved per device, there is always one to wait for
         }
+    }
+
+    HipResult NewResources(int dev, Resources* out)
+    {
+        Resources r;
+        HipResult st = vkmr_hip_device_alloc(dev, m_scratch_bytes, &r.scratch);
+        if (st == VKMR_OK) st = vkmr_hip_event_create(dev, &r.begin);
+        if (st == VKMR_OK) st = vkmr_hip_event_create(dev, &r.done);
+        if (st != VKMR_OK) {
+            FreeResources(dev, r);
+            return st;
+        }
+        ++m_allocations;
+        *out = r;
+        return VKMR_OK;
     }
 
     // Room for entry `slot` of the device's root array (grows by doubling; the reductions of this
