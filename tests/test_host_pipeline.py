@@ -161,3 +161,34 @@ def test_hip_all_combine_failure_is_loud(fake_vkmr, native, golden):
     r, out, m = run(fake_vkmr, "hip:all", stream_of(native, s), VKMR_SLICE_LOG2=6, VKMR_FAKE_DEVICES=4, VKMR_FAKE_FAIL_REDUCE=17)
     assert m is None or m["root"] == ""
     assert b"Failed to combine the slice roots" in r.stderr
+
+
+def test_parallel_packer_in_the_pipeline_under_tsan(native, golden, tmp_path):
+    """The fork-join packer feeding the stream processor (mapped file, spans cut at line ends, parts packed at their
+    prefix offsets into the pinned batch) under ThreadSanitizer, end to end through the fake ABI."""
+    os.makedirs(OUT, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", CSRC]
+    tsan = ["-fsanitize=thread", "-g", "-O1"]
+    lib = os.path.join(OUT, "tsan", "libvkmr_hip.so")
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    lib_src = [os.path.join(ROOT, "tests", "c", "fake_vkmr_hip.cpp"), os.path.join(HOST, "cpu_sha256d.cpp")]
+    files = ["vkmr_main.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "inputs.cpp", "batches.cpp", "slices.cpp", "mappings.cpp", "reductions.cpp",
+             "stream_pack.cpp"]
+    srcs = [os.path.join(HOST, f) for f in files]
+    exe = os.path.join(OUT, "tsan", "vkmr_tsan")
+    deps = srcs + lib_src + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "vkmr_hip.h")]
+    if not _newer(exe, deps):
+        subprocess.check_call(["g++", "-std=c++17", "-shared", "-fPIC"] + tsan + inc + lib_src + ["-o", lib])
+        subprocess.check_call(["g++", "-std=c++17", "-pthread"] + tsan + inc + srcs + ["-o", exe, "-L", os.path.dirname(lib), "-lvkmr_hip",
+                               "-Wl,-rpath," + os.path.dirname(lib)])
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    path = tmp_path / "g3.txt"
+    path.write_bytes(stream_of(native, s))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VKMR_") and k != "LD_PRELOAD"}
+    env.update(LD_LIBRARY_PATH=os.path.dirname(lib), VKMR_PACK_THREADS="6", VKMR_BATCH_MB="8", VKMR_SLICE_LOG2="17", VKMR_INPUT_SPAN_MB="4",
+               TSAN_OPTIONS="halt_on_error=0")
+    with open(path, "rb") as f:
+        r = subprocess.run([exe, "hip:0"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:].decode()
+    m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
+    assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])
