@@ -293,7 +293,10 @@ def main():
             local_rank = 0
         else:
             if torch.cuda.device_count() <= local_rank:
-                raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+                isolated = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+                if not (isolated and torch.cuda.device_count() == 1):
+                    raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+                local_rank = 0   # the launcher gave this rank its own GPU through *_VISIBLE_DEVICES (RCCL refuses two ranks on one GPU)
             collective = "nccl"   # torch.distributed's nccl backend IS RCCL on ROCm; any failure here ends the run
             torch.cuda.set_device(local_rank)
             tdev = torch.device("cuda", local_rank)

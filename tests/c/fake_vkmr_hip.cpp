@@ -10,6 +10,7 @@
 //   VKMR_FAKE_EVENT_POLLS=p    an event reports VKMR_NOT_READY to its first p queries (asynchrony; default 2)
 //   VKMR_FAKE_FAIL_EVENT=i     the i-th event completion (1-based, over all events) reports a device error
 //   VKMR_FAKE_FAIL_REDUCE=i    the i-th vkmr_hip_reduce_async call fails at dispatch
+//   VKMR_FAKE_NO_HASH=1        map and reduce write nothing (host-side timing of the pipeline only; roots are garbage)
 // "Device" memory is host memory and every *_async call completes at once; hashing is done with the product's
 // own "CPU" backend functions (csrc/host/cpu_sha256d.cpp), never with the oracle.  Scratch buffers are checked
 // against the schedule of the real library (csrc/reduce_plan.hpp): a reduction whose scratch is smaller than
@@ -245,7 +246,8 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream, const uint32_t* data, uint6
     if (!dev_ok(dev) || !meta || !out) return fail(VKMR_ERR_INVALID, "map: bad argument");
     if (room_at(meta) < (size_t)count * 8 || room_at(out) < (size_t)count * 32 || (data_words && room_at(data) < data_words * 4))
         return fail(VKMR_ERR_INVALID, "map: a buffer is not (large enough) device memory");
-    for (uint32_t i = 0; i < count; ++i) {
+    static const bool no_hash = env_long("VKMR_FAKE_NO_HASH", 0) != 0;
+    for (uint32_t i = 0; i < count && !no_hash; ++i) {
         uint64_t size = meta[i].size;
         const uint64_t avail = meta[i].start < data_words ? (data_words - meta[i].start) * 4 : 0;   // same cut as the kernel
         if (size > avail) size = avail;
@@ -268,7 +270,7 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream, const vkmr_digest* diges
     if (room_at(digests) < count * 32 || room_at(root) < 32) return fail(VKMR_ERR_INVALID, "reduce: a buffer is not device memory");
     const uint64_t cells = vkmr_plan::cells_written(count, 1);   // what the real launch sequence writes
     if (cells && room_at(scratch) < cells * 32) return fail(VKMR_ERR_INVALID, "reduce: scratch smaller than the real kernels need");
-    do_reduce(digests, count, height, root);
+    if (env_long("VKMR_FAKE_NO_HASH", 0) == 0) do_reduce(digests, count, height, root);
     return VKMR_OK;
 }
 
