@@ -290,12 +290,13 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     static const int tile_override = [] { const char* e = getenv("VKMR_MAP_TILE"); return e ? atoi(e) : 0; }();   // experiments only
     if (tile_override >= 64 && tile_override <= 2048) tile = (uint32_t)tile_override & ~63u;
     const uint32_t grid = (uint32_t)(((uint64_t)count + tile - 1) / tile);   // count + tile can pass 2^32
+    static const int dyn_lds = [] { const char* e = getenv("VKMR_MAP_DYNLDS"); return e ? atoi(e) : 0; }();   // experiments only: caps occupancy
     auto launch_direct = [&](bool fullfast) {
         if (fullfast) {
             if (tile >= 1024u)
-                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, true>), dim3(grid), dim3(512), (size_t)dyn_lds, S(s), data_dev, data_words, meta_dev, count, out, tile);
             else
-                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, true>), dim3(grid), dim3(256), (size_t)dyn_lds, S(s), data_dev, data_words, meta_dev, count, out, tile);
         } else {
             if (tile >= 1024u)
                 hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, false>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
