@@ -166,7 +166,58 @@ void Batches::Free(Buffers& b)
 
 Batches::~Batches()
 {
+    JoinPrefetch();
     for (auto& b : m_free) Free(b);
+}
+
+void Batches::JoinPrefetch()
+{
+    if (!m_prefetch.joinable()) return;
+    m_stop = true;   // at most the allocation in progress is waited for
+    m_prefetch.join();
+    m_stop = false;
+}
+
+bool Batches::Allocate(size_t words, size_t count, Buffers* out)
+{
+    void *h1 = nullptr, *h2 = nullptr, *d1 = nullptr, *d2 = nullptr;
+    const bool ok = vkmr_hip_host_alloc(words * 4, &h1) == VKMR_OK && vkmr_hip_host_alloc(count * sizeof(vkmr_metadata), &h2) == VKMR_OK &&
+                    vkmr_hip_device_alloc(m_dev, words * 4, &d1) == VKMR_OK &&
+                    vkmr_hip_device_alloc(m_dev, count * sizeof(vkmr_metadata), &d2) == VKMR_OK;
+    if (!ok) {   // the caller waits for a mapping to retire and tries again, or reports the failure
+        vkmr_hip_host_free(h1); vkmr_hip_host_free(h2);
+        vkmr_hip_device_free(m_dev, d1); vkmr_hip_device_free(m_dev, d2);
+        return false;
+    }
+    *out = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1), static_cast<vkmr_metadata*>(d2), words, count};
+    return true;
+}
+
+void Batches::Prefetch(size_t n)
+{
+    JoinPrefetch();
+    if (n == 0) return;
+    const size_t words = m_words, count = m_count;
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        m_pending = n;
+    }
+    m_prefetch = std::thread([this, n, words, count] {
+        for (size_t i = 0; i < n; ++i) {
+            Buffers buf;
+            const bool ok = !m_stop && Allocate(words, count, &buf);
+            std::lock_guard<std::mutex> lock(m_mu);
+            if (ok) {
+                m_free.push_back(buf);
+                ++m_allocations;
+                --m_pending;
+            } else {
+                m_pending = 0;   // out of memory: the owner allocates (and reports) for itself
+            }
+            m_cv.notify_all();
+            if (!ok) return;
+        }
+    });
 }
 
 void Batches::Reshape(size_t data_bytes, size_t meta_count)
@@ -174,6 +225,7 @@ void Batches::Reshape(size_t data_bytes, size_t meta_count)
     size_t words = data_bytes / 4;
     if (words > 0xFFFFFFFFull) words = 0xFFFFFFFFull;
     if (words == 0 || meta_count == 0 || (words == m_words && meta_count == m_count)) return;
+    JoinPrefetch();
     m_words = words;
     m_count = meta_count;
     for (auto& b : m_free) Free(b);   // idle buffers of the old shape
@@ -184,22 +236,19 @@ Batch Batches::New()
 {
     Batch b;
     Buffers buf = {nullptr, nullptr, nullptr, nullptr, 0, 0};
-    if (!m_free.empty()) {
-        buf = m_free.back();
-        m_free.pop_back();
-    } else {
-        void *h1 = nullptr, *h2 = nullptr, *d1 = nullptr, *d2 = nullptr;
-        const bool ok = vkmr_hip_host_alloc(m_words * 4, &h1) == VKMR_OK &&
-                        vkmr_hip_host_alloc(m_count * sizeof(vkmr_metadata), &h2) == VKMR_OK &&
-                        vkmr_hip_device_alloc(m_dev, m_words * 4, &d1) == VKMR_OK &&
-                        vkmr_hip_device_alloc(m_dev, m_count * sizeof(vkmr_metadata), &d2) == VKMR_OK;
-        if (!ok) {   // the caller waits for a mapping to retire and tries again, or reports the failure
-            vkmr_hip_host_free(h1); vkmr_hip_host_free(h2);
-            vkmr_hip_device_free(m_dev, d1); vkmr_hip_device_free(m_dev, d2);
-            return b;
+    bool have = false;
+    {
+        std::unique_lock<std::mutex> lock(m_mu);
+        m_cv.wait(lock, [&] { return !m_free.empty() || m_pending == 0; });   // a prefetched batch is on its way
+        if (!m_free.empty()) {
+            buf = m_free.back();
+            m_free.pop_back();
+            have = true;
         }
-        buf = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1),
-               static_cast<vkmr_metadata*>(d2), m_words, m_count};
+    }
+    if (!have) {
+        if (!Allocate(m_words, m_count, &buf)) return b;
+        std::lock_guard<std::mutex> lock(m_mu);
         ++m_allocations;
     }
     b.m_owner = this; b.m_dev = m_dev;
@@ -213,10 +262,12 @@ Batch Batches::New()
 void Batches::Recycle(Batch& b)
 {
     Buffers buf = {b.m_data, b.m_meta, b.m_ddata, b.m_dmeta, b.m_cap_words, b.m_cap_count};
-    if (buf.words == m_words && buf.count == m_count)
+    if (buf.words == m_words && buf.count == m_count) {
+        std::lock_guard<std::mutex> lock(m_mu);
         m_free.push_back(buf);
-    else
+    } else {
         Free(buf);   // shape changed since this batch was handed out
+    }
     --m_live;
 }
 

@@ -9,9 +9,13 @@
 // instead of being returned to the system after every mapping (the reference frees
 // them, src/vkmr/Mappings.cpp:328-329; recycling is its first to-do, README.md:113).
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "stream_pack.hpp"
@@ -91,7 +95,11 @@ public:
     Batches(const Batches&) = delete;
     Batches& operator=(const Batches&) = delete;
 
-    Batch New();                 // a fresh or recycled batch; falsy when allocation fails
+    // Starts allocating `n` batches of the current shape on a helper thread.  Pinning 80 MiB of host memory takes
+    // 10-15 ms; a stream that needs five batches would otherwise spend 60 ms of its first 100 allocating on the
+    // thread that should be packing (profiles/r02_hip_api_stats_256_slices.csv).
+    void Prefetch(size_t n);
+    Batch New();                 // a prefetched, recycled or fresh batch; falsy when allocation fails
     void Recycle(Batch& b);      // called by Batch::Release
     size_t InCirculation() const { return m_live; }
     size_t Allocations() const { return m_allocations; }
@@ -104,10 +112,18 @@ public:
 private:
     struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; size_t words, count; };
     void Free(Buffers& b);
+    bool Allocate(size_t words, size_t count, Buffers* out);
+    void JoinPrefetch();
     int m_dev;
     size_t m_words, m_count, m_live, m_allocations = 0;
     uint32_t m_next;
     std::vector<Buffers> m_free;
+    // the prefetch thread and the owner share m_free, m_pending and m_allocations under m_mu
+    std::mutex m_mu;
+    std::condition_variable m_cv;
+    std::thread m_prefetch;
+    size_t m_pending = 0;        // batches the prefetch thread has still to deliver
+    std::atomic<bool> m_stop{false};
 };
 
 }  // namespace vkmr

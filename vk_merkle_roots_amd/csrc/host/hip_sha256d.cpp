@@ -28,7 +28,7 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        c.pack_threads = hw == 0 ? 1u : (hw > 8u ? 8u : hw);
+        c.pack_threads = hw == 0 ? 1u : (hw > 16u ? 16u : hw);
     }
     if (c.slice_log2 < 1) c.slice_log2 = 1;
     if (c.slice_log2 > 40) c.slice_log2 = 40;   // beyond HBM: the allocation fails and Add() reports it
@@ -177,6 +177,7 @@ void HipSha256D::Instance::AdaptBatchSize(const Batch& sent)
     want = (want + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
     if (want > m_cfg.batch_bytes_max) want = m_cfg.batch_bytes_max;
     Batches& pool = *Dev(sent.Device()).batches;
+    if (want > 4 * pool.DataBytes()) want = 4 * pool.DataBytes();   // by steps: the stream may be about to end
     if (want > pool.DataBytes() + pool.DataBytes() / 2) {
         if (m_cfg.verbose) std::cout << "Strings average " << avg - 4 << " bytes: batches of " << (want >> 20) << " MiB from now on." << std::endl;
         pool.Reshape(want, (size_t)1 << 20);
@@ -190,6 +191,12 @@ bool HipSha256D::Instance::MapCurrent()
     if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
     PerDevice& pd = Dev(slice.Device());
     AdaptBatchSize(m_batch);
+    if (!pd.prefetched && !m_draining && m_batch.Words() * 4 >= pd.batches->DataBytes() / 2) {
+        // the first batch of this device went out (about) full and the stream goes on: it will need the rest of the
+        // pipeline's batches too -- pin them on a helper thread while this one keeps packing
+        pd.prefetched = true;
+        pd.batches->Prefetch(m_cfg.max_inflight);
+    }
     return m_mappings->Map(std::move(m_batch), slice.Sub(), pd.map_stream) == VKMR_OK;
 }
 
@@ -314,6 +321,7 @@ ISha256D::out_type HipSha256D::Instance::Root()
 {
     if (!m_ok) return "";
     // residual batch, then every mapping (reference SHA-256vk.cpp:291-299)
+    m_draining = true;
     const bool single = m_slices.LastNumber() <= 1;
     if (!MapCurrent()) return "";
     Account(m_mappings->WaitFor());

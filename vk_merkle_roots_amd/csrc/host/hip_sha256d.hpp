@@ -28,7 +28,8 @@ struct HipConfig {
     size_t slice_budget = 0;         // slices resident per device at most (0 = max_inflight + 1: the one being filled
                                      // plus one per mapping in flight); when used up, Add() blocks on the oldest
                                      // reduction and re-uses its slice instead of allocating another
-    unsigned pack_threads = 0;       // threads packing large input spans (0 = min(8, hardware threads))
+    unsigned pack_threads = 0;       // threads packing large input spans (0 = min(16, hardware threads): 0.23 s with 8,
+                                     // 0.20 s with 16 on 2^25 strings, profiles/r02_end_to_end_stdin.txt)
     bool verbose = false;            // per-op log lines like the reference prints
     static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_BATCH_MAX_MB, VKMR_MAX_INFLIGHT,
                                      // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_VERBOSE
@@ -67,6 +68,7 @@ private:
         int dev;
         vkmr_stream map_stream = nullptr, reduce_stream = nullptr;
         std::unique_ptr<Batches> batches;
+        bool prefetched = false;   // the pipeline's batches have been requested from the helper thread
     };
     PerDevice& Dev(int dev);
     bool MapCurrent();                                   // dispatches m_batch into the current slice's pending reservations
@@ -85,6 +87,7 @@ private:
     std::unique_ptr<Reductions> m_reductions;
     std::unique_ptr<class ForkJoin> m_pool;   // packs large input spans in parallel
     bool m_ok;
+    bool m_draining = false;   // Root() has begun: nothing more will be packed
 };
 
 }  // namespace vkmr
