@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -67,7 +68,7 @@ size_t room_at(const void* p)
 
 bool dev_ok(int dev) { return dev >= 0 && dev < n_devices(); }
 
-struct Event { int polls_left = 0; bool recorded = false; bool failed = false; };
+struct Event { int polls_left = 0; bool recorded = false; bool failed = false; double at_ms = 0.0; };
 long g_completions = 0, g_reduces = 0;
 
 void do_reduce(const vkmr_digest* in, uint64_t count, uint32_t height, vkmr_digest* root)
@@ -203,6 +204,7 @@ vkmr_status vkmr_hip_event_record(int, vkmr_event e, vkmr_stream)
     Event* ev = reinterpret_cast<Event*>(e);
     ev->recorded = true;
     ev->failed = false;
+    ev->at_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ev->polls_left = (int)env_long("VKMR_FAKE_EVENT_POLLS", 2);
     return VKMR_OK;
 }
@@ -233,9 +235,11 @@ vkmr_status vkmr_hip_event_wait(int, vkmr_event e)
     return complete(ev);
 }
 vkmr_status vkmr_hip_stream_wait_event(int, vkmr_stream, vkmr_event) { return VKMR_OK; }
-vkmr_status vkmr_hip_event_elapsed_ms(int, vkmr_event, vkmr_event, float* ms)
+vkmr_status vkmr_hip_event_elapsed_ms(int, vkmr_event b, vkmr_event e, float* ms)
 {
-    if (ms) *ms = 0.f;
+    if (!b || !e || !ms) return fail(VKMR_ERR_INVALID, "event_elapsed_ms");
+    const double d = reinterpret_cast<Event*>(e)->at_ms - reinterpret_cast<Event*>(b)->at_ms;   // host time between the two records
+    *ms = (float)(d > 1e-6 ? d : 1e-6);
     return VKMR_OK;
 }
 
@@ -315,6 +319,81 @@ vkmr_status vkmr_hip_roots_in_slice_order_async(int, vkmr_stream, const vkmr_dig
     if (room_at(out) < (size_t)total * 32) return fail(VKMR_ERR_INVALID, "slice_order: output too small");
     for (uint32_t k = 0; k < total; ++k) out[k] = gathered[(size_t)(k % nranks) * per_rank + k / nranks];
     return VKMR_OK;
+}
+
+// ---- the rest of the header, so that the ctypes stub (which binds every declared symbol) and bench.py can run on the double ----
+
+size_t vkmr_hip_reduce_slices_scratch_bytes(uint64_t capacity, uint32_t nslices)
+{
+    if (nslices == 0) nslices = 1;
+    return (size_t)vkmr_plan::cells_upper_bound(capacity, nslices) * nslices * sizeof(vkmr_digest);
+}
+
+vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_digest* digests, uint32_t nslices, uint64_t capacity,
+                                         uint64_t count_last, uint32_t height, void* scratch, vkmr_digest* roots)
+{
+    if (!digests || !roots || nslices == 0 || count_last == 0 || count_last > capacity) return fail(VKMR_ERR_INVALID, "reduce_slices: bad argument");
+    if (capacity > 128 && room_at(scratch) < vkmr_plan::cells_written(nslices == 1 ? count_last : capacity, nslices) * nslices * 32)
+        return fail(VKMR_ERR_INVALID, "reduce_slices: scratch smaller than the real kernels need");
+    for (uint32_t k = 0; k < nslices; ++k) {
+        const uint64_t n = (k + 1 == nslices) ? count_last : capacity;
+        if (vkmr_plan::ceil_shift(n, height) != 1) return fail(VKMR_ERR_INVALID, "reduce_slices: height");
+        if (room_at(digests + (uint64_t)k * capacity) < n * 32 || room_at(roots + k) < 32) return fail(VKMR_ERR_INVALID, "reduce_slices: not device memory");
+        do_reduce(digests + (uint64_t)k * capacity, n, height, roots + k);
+    }
+    (void)dev; (void)s;
+    return VKMR_OK;
+}
+
+size_t vkmr_hip_reduce_levels_scratch_bytes(uint64_t count) { return (size_t)(vkmr_plan::ceil_shift(count, 1) + vkmr_plan::ceil_shift(count, 2) + 2) * 32; }
+vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_digest* digests, uint64_t count, uint32_t height, void* scratch,
+                                         vkmr_digest* root)
+{
+    if (!scratch) return fail(VKMR_ERR_INVALID, "reduce_levels: null scratch");
+    if (!dev_ok(dev) || !digests || !root || count == 0 || height > 63 || vkmr_plan::ceil_shift(count, height) != 1)
+        return fail(VKMR_ERR_INVALID, "reduce_levels: bad argument");
+    (void)s;
+    do_reduce(digests, count, height, root);
+    return VKMR_OK;
+}
+
+vkmr_status vkmr_hip_proof_async(int, vkmr_stream, const vkmr_digest*, uint64_t, uint32_t, uint64_t, void*, vkmr_digest*, vkmr_digest*)
+{
+    return fail(VKMR_ERR_INVALID, "proof: not provided by the fake ABI");
+}
+
+vkmr_status vkmr_hip_comm_create_id(void* id)
+{
+    if (!id) return fail(VKMR_ERR_INVALID, "comm_create_id");
+    memset(id, 0x5A, VKMR_COMM_ID_BYTES);
+    return VKMR_OK;
+}
+vkmr_status vkmr_hip_comm_init_rank(int dev, const void* id, int nranks, int rank, vkmr_comm* out)
+{
+    if (!id || !out || nranks != 1 || rank != 0 || !dev_ok(dev)) return fail(VKMR_ERR_COMM, "comm_init_rank: the fake ABI has no cross-process transport");
+    vkmr_comm_s* c = new vkmr_comm_s;
+    c->devs.push_back(dev);
+    *out = c;
+    return VKMR_OK;
+}
+vkmr_status vkmr_hip_comm_size(vkmr_comm c, int* nranks, int* nlocal)
+{
+    if (!c) return fail(VKMR_ERR_INVALID, "comm_size");
+    if (nranks) *nranks = (int)c->devs.size();
+    if (nlocal) *nlocal = (int)c->devs.size();
+    return VKMR_OK;
+}
+
+void vkmr_hip_digest_hex(const vkmr_digest* d, char* hex)
+{
+    static const char digits[] = "0123456789abcdef";
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 4; ++b) {
+            const unsigned v = (d->data[i] >> (24 - 8 * b)) & 0xffu;
+            hex[8 * i + 2 * b] = digits[v >> 4];
+            hex[8 * i + 2 * b + 1] = digits[v & 15u];
+        }
+    hex[64] = 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,81 @@
+"""bench.py's orchestration on a CPU-only machine: the JSON contract, the slice/height/combine logic, the self-spawned
+N-rank launch and its labelled gloo rehearsal -- driven through the test double of the C ABI (tests/c/fake_vkmr_hip.cpp,
+selected with VKMR_HIP_LIB, the same switch tools/ab.sh uses for A/B builds).  Hashing in the double is done by the
+product's own CPU functions, so the roots are real and are compared with the oracle; the timings mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc", "host")
+CSRC = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc")
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "root"]
+
+
+@pytest.fixture(scope="session")
+def fake_lib(native):
+    out = os.path.join(ROOT, "tests", "_build", "fake_plain")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libvkmr_hip.so")
+    srcs = [os.path.join(ROOT, "tests", "c", "fake_vkmr_hip.cpp"), os.path.join(HOST, "cpu_sha256d.cpp")]
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs + [os.path.join(CSRC, "reduce_plan.hpp")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", CSRC] + srcs + ["-o", lib])
+    return lib
+
+
+def run_bench(fake_lib, *args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["VKMR_HIP_LIB"] = fake_lib
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pipeline", "--no-long-strings"] + list(args),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    return r
+
+
+def oracle_root(oracle, seed, n):
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(seed, n, 127)
+    return oracle.root(oracle.leaves_packed(b.data, b.meta, threads=4), threads=4)
+
+
+@pytest.mark.parametrize("extra", [[], ["--slice-log2", "10"], ["--batch-log2", "11"], ["--slice-log2", "9", "--batch-log2", "12", "--levels-variant"]])
+def test_bench_line_contract_and_root(fake_lib, oracle, extra):
+    r = run_bench(fake_lib, "--leaves-log2", "13", "--steps", "2", "--warmup", "1", *extra)
+    assert r.returncode == 0, r.stderr[-1500:].decode()
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1, "stdout must carry the one JSON line and nothing else"
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and "workload" in d["config"]
+    assert "roofline_reduce" in d and d["config"]["leaves_per_gpu"] == 1 << 13
+    assert d["root"] == oracle.hex(oracle_root(oracle, 42, 1 << 13))
+    assert d["sub_roots"] == [d["root"]] and d["root_matches_golden"] is None      # the golden file covers 2^26 only
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_spawns_its_ranks_and_combines_in_rank_order(fake_lib, oracle, n):
+    """`python bench.py --gpus N --rehearse-gloo`: the script starts the N ranks itself (no launcher), rank r hashes
+    rndm 42+r, the sub-roots are gathered in rank order and combined with the duplicate-last rule."""
+    r = run_bench(fake_lib, "--gpus", str(n), "--rehearse-gloo", "--leaves-log2", "12", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-1500:].decode()
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["ranks"] == n and "REHEARSAL" in d["config"]["collective"]
+    subs = np.stack([oracle_root_words for oracle_root_words in (oracle.reduce_height(_leaves(oracle, 42 + k, 1 << 12), 12) for k in range(n))])
+    assert d["sub_roots"] == [oracle.hex(s) for s in subs]
+    assert d["root"] == oracle.hex(oracle.root(subs))
+    assert d["value"] > 0 and d["config"]["leaves_total"] == n << 12
+
+
+def _leaves(oracle, seed, n):
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(seed, n, 127)
+    return oracle.leaves_packed(b.data, b.meta, threads=4)
