@@ -243,13 +243,19 @@ def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=5):
     blocks = int(((sizes + 8) // 64 + 1).sum())
     nbytes = b.words * 4 + 40 * n
     ops = blocks * SLOTS_BLOCK + n * SLOTS_DIGEST
-    # a checksum of the digests that the parity tests can reproduce (tests/test_gpu_fullsize.py checks every digest)
     for buf in (d_data, d_meta, d_out):
         buf.free()
+    traffic = None   # HBM bytes per launch from the PMC passes over the same workload (tools/run_n.sh -> profiles/pmc_latest.json)
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if rec.get("long_strings_workload") == f"rndm {seed} 2^{count_log2} {maxlen}, one batch" and not os.environ.get("VKMR_MAP_VARIANT"):
+            traffic = rec.get("long_strings_map_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     return {"workload": f"rndm {seed} 2^{count_log2} {maxlen}, one batch", "strings": n, "input_bytes": int(b.words * 4), "map_ms": ms,
-            "leaf_hashes_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "kernel": "map_kernel (per-lane dwordx4 mode)", "achieved": nbytes / (ms * 1e-3) / 1e9,
+            "leaf_hashes_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "kernel": "map_kernel (line-window mode)", "achieved": nbytes / (ms * 1e-3) / 1e9,
                                                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                               "algorithmic_bytes_per_launch": int(nbytes)},
+                                                               "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes)},
             "valu_achieved_tops": ops / (ms * 1e-3) / 1e12, "compressions_per_string": blocks / n + 1}
 
 

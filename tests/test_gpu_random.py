@@ -77,3 +77,43 @@ def test_random_map_length_mixes(gpu, oracle):
         got = gpu.leaf_digests(b)
         want = oracle.leaves_packed(b.data, b.meta, threads=16)
         assert (got == want).all(), (case, kind, n)
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5"])
+def test_every_fetch_mode_of_the_map_kernel_is_bit_exact(variant):
+    """The map kernel's alternative fetch modes (VKMR_MAP_VARIANT, read once per process: LDS-staged 64 / 32 KiB tiles,
+    per-wavefront gather, per-lane 16-byte loads, line window) against the oracle on short, long, ragged, unordered and
+    out-of-range inputs -- whichever mode a launch picks, the digests are the same."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import vk_merkle_roots_amd as vk
+from conftest import Oracle, golden_pattern
+from test_gpu_parity import batch_of
+o, gpu = Oracle(), vk.HipDevice(0)
+for seed, n, maxlen in ((3, 70000, 127), (5, 3000, 4096), (6, 9000, 700), (7, 4000, 2), (8, 150000, 300)):
+    b = vk.rndm_packed(seed, n, maxlen)
+    assert (gpu.leaf_digests(b) == o.leaves_packed(b.data, b.meta, threads=8)).all(), (seed, n, maxlen)
+b = batch_of([golden_pattern(k, 9 + k) for k in range(0, 400)] + [golden_pattern(k, k) for k in (4095, 4096, 4097, 8191, 70000)])
+assert (gpu.leaf_digests(b) == o.leaves_packed(b.data, b.meta)).all()
+b = vk.rndm_packed(31, 6000, 1500)
+perm = np.random.default_rng(1).permutation(6000)
+meta = b.meta[perm].copy()
+meta[5] = (b.words - 1, 64); meta[6] = (b.words + 99, 7); meta[7] = (b.words - 3, 0xFFFFFFF0)
+cut = meta.copy(); cut[5, 1] = 4; cut[6] = (0, 0); cut[7, 1] = 12
+got = gpu.leaf_digests(vk.PackedBatch(b.data, meta, b.words, 0))
+assert (got == o.leaves_packed(b.data, cut)).all()
+# a batch that does not start on a 128-byte boundary (sub-buffer of a larger allocation)
+d_all = gpu.upload(np.concatenate([np.zeros(5, np.uint32), b.data]))
+d_meta, d_out = gpu.upload(b.meta), gpu.alloc(32 * b.count)
+vk.check(gpu.lib.vkmr_hip_map_async(gpu.index, gpu.stream, d_all.at(20), b.words, d_meta.ptr, b.count, d_out.ptr), "map")
+assert (gpu.download(d_out, 32 * b.count).reshape(-1, 8) == o.leaves_packed(b.data, b.meta, threads=8)).all()
+print("ok")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, VKMR_MAP_VARIANT=variant)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr[-2000:].decode()

@@ -38,6 +38,30 @@ __global__ __launch_bounds__(256) void calib_pairs_t(const uint4* __restrict__ i
     if (x == 0x12345678u) out[0] = x;
 }
 
+// The long-string map kernel's walk, without the hashing: lane i streams through its own 2 KiB region.
+//   walk64    64 bytes per step from a 4-byte-aligned start (what the per-lane dwordx4 mode does: 4 loads per block)
+//   walk128   128-byte lines, line-aligned, one line per step (8 loads): every line is requested exactly once
+// WAVES_APART = how far apart in time the steps of one lane are is set by `spin` dependent VALU ops between steps.
+template <int BYTES_PER_STEP, bool ALIGNED>
+__global__ __launch_bounds__(256) void calib_walk(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t region_words, int spin)
+{
+    const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t start = lane * region_words + (ALIGNED ? 0 : (lane * 7u) % 32u);   // word index
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t acc = 0;
+    constexpr int WORDS = BYTES_PER_STEP / 4;
+    for (uint32_t w = 0; w + WORDS <= region_words - 32; w += WORDS) {
+        const u32x4_u* p = reinterpret_cast<const u32x4_u*>(in + start + w);
+#pragma unroll
+        for (int q = 0; q < WORDS / 4; ++q) {
+            const u32x4_u v = p[q];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+        for (int k = 0; k < spin; ++k) acc = acc * 1664525u + 1013904223u;   // dependent chain: the "hash" between steps
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main(int argc, char** argv)
 {
     const size_t bytes = (argc > 1 ? (size_t)atol(argv[1]) : 1024) << 20;
@@ -52,6 +76,31 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(calib_pairs_t, dim3((unsigned)(bytes / 64 / 256)), dim3(256), 0, 0, in, out);
     }
     hipDeviceSynchronize();
+    // the walks: 2^21 lanes x 2 KiB = 4 GiB (needs the 4 GiB buffer: run with argument 4096)
+    if (bytes >= ((size_t)4 << 30)) {
+        const uint32_t region_words = 512;
+        const unsigned grid = (unsigned)((bytes / 4 / region_words) / 256);
+        for (int spin : {0, 400}) {
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEvent_t e[5];
+                for (auto& x : e) hipEventCreate(&x);
+                hipEventRecord(e[0], 0);
+                hipLaunchKernelGGL((calib_walk<64, false>), dim3(grid), dim3(256), 0, 0, reinterpret_cast<const uint32_t*>(in), out, region_words, spin);
+                hipEventRecord(e[1], 0);
+                hipLaunchKernelGGL((calib_walk<64, true>), dim3(grid), dim3(256), 0, 0, reinterpret_cast<const uint32_t*>(in), out, region_words, spin);
+                hipEventRecord(e[2], 0);
+                hipLaunchKernelGGL((calib_walk<128, true>), dim3(grid), dim3(256), 0, 0, reinterpret_cast<const uint32_t*>(in), out, region_words, spin);
+                hipEventRecord(e[3], 0);
+                hipLaunchKernelGGL((calib_walk<128, false>), dim3(grid), dim3(256), 0, 0, reinterpret_cast<const uint32_t*>(in), out, region_words, spin);
+                hipEventRecord(e[4], 0);
+                hipDeviceSynchronize();
+                float a, b, c, d;
+                hipEventElapsedTime(&a, e[0], e[1]); hipEventElapsedTime(&b, e[1], e[2]); hipEventElapsedTime(&c, e[2], e[3]); hipEventElapsedTime(&d, e[3], e[4]);
+                printf("walk over %u lanes x 2 KiB, spin %d: 64 B unaligned %.3f ms | 64 B aligned %.3f ms | 128 B line-aligned %.3f ms | 128 B unaligned %.3f ms\n",
+                       grid * 256, spin, a, b, c, d);
+            }
+        }
+    }
     printf("each kernel read %zu bytes\n", bytes);
     return 0;
 }

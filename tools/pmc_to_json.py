@@ -23,6 +23,8 @@ def main():
     p.add_argument("--maxlen", type=int, default=127)
     p.add_argument("--slice-log2", type=int, default=26)
     p.add_argument("--launches-per-step", type=int, default=1)
+    p.add_argument("--long-strings-dir", default=None,
+                   help="FETCH_SIZE and WRITE_SIZE passes over tools/long_strings_probe.py (rndm 42 2^21 4096, one batch): adds the long_strings_* keys")
     a = p.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), recursive=True):
@@ -60,6 +62,19 @@ def main():
         res["reduce_hbm_read_bytes_per_step"] = red_read / steps
         res["reduce_hbm_write_bytes_per_step"] = red_write / steps
         res["reduce_hbm_bytes_per_step"] = (red_read + red_write) / steps
+    if a.long_strings_dir:
+        ls = collections.defaultdict(list)
+        for path in glob.glob(os.path.join(a.long_strings_dir, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                if "map_kernel" in r["Kernel_Name"]:
+                    ls[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if ls.get("FETCH_SIZE") and ls.get("WRITE_SIZE"):
+            rd = sum(ls["FETCH_SIZE"]) / len(ls["FETCH_SIZE"]) * 1024 * 2
+            wr = sum(ls["WRITE_SIZE"]) / len(ls["WRITE_SIZE"]) * 1024
+            res["long_strings_workload"] = "rndm 42 2^21 4096, one batch"
+            res["long_strings_map_hbm_read_bytes_per_launch"] = rd
+            res["long_strings_map_hbm_write_bytes_per_launch"] = wr
+            res["long_strings_map_hbm_bytes_per_launch"] = rd + wr
     json.dump(res, open(a.out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 

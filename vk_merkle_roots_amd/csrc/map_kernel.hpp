@@ -41,6 +41,8 @@ using vkmr_dev::Node;
 #define VKMR_MAP_STAGE_PAD 32
 #define VKMR_MAP_GATHER_STRIDE 20   // words per string row in the gather area: 80 B keeps ds_read_b128 conflict-free
 #define VKMR_MAP_BINS 64
+#define VKMR_MAP_WIN_STRIDE 68      // words per lane row of the line window: two 32-word lines + 4, so that the
+                                    // ds_write_b128 of 16 consecutive lanes lands on all 64 banks
 
 #ifdef VKMR_MAP_STAMPS
 // Diagnostic build only (tools/map_stamps.py): per-phase shader-clock totals of the map
@@ -50,6 +52,30 @@ __device__ unsigned long long g_map_stamps[32768 * 8];   // 8 words per workgrou
 #else
 #define VKMR_STAMP(var)
 #endif
+
+// One 128-byte line of the packed buffer, `li` = its first word's index (a multiple of 32 words counted from a
+// 128-byte-aligned address; negative for the line that contains data[0] when the buffer itself is not aligned).
+// Words outside [0, data_words) read as zero.  `want` = this lane needs the line at all.
+__device__ __forceinline__ void load_line(const uint32_t* __restrict__ data, uint64_t data_words, long long li, bool want, uint4 (&R)[8])
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) R[q] = make_uint4(0u, 0u, 0u, 0u);
+    if (!want) return;
+    if (li >= 0 && (unsigned long long)li + 32ull <= data_words) {
+        const uint4* src = reinterpret_cast<const uint4*>(data + li);   // 128-byte aligned by construction
+#pragma unroll
+        for (int q = 0; q < 8; ++q) R[q] = src[q];
+    } else {   // the first or the last line of the buffer: word by word
+        uint32_t t[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const long long idx = li + j;
+            t[j] = (idx >= 0 && (unsigned long long)idx < data_words) ? data[idx] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) R[q] = make_uint4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+    }
+}
 
 __device__ __forceinline__ uint32_t block_count(uint32_t size) { return (uint32_t)(((uint64_t)size + 8u) >> 6) + 1u; }
 
@@ -66,7 +92,9 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
 {
     constexpr int VKMR_MAP_THREADS = THREADS, VKMR_MAP_MAX_TILE = MAX_TILE, VKMR_MAP_STAGE_WORDS = STAGE_WORDS;
     constexpr bool GATHER = (MODE == 1);   // MODE 0: stage tiles in LDS; 1: per-wavefront gather; 2: per-lane 16-byte loads
+    constexpr bool LINEWIN = (MODE == 4);  // per-lane line-aligned loads through a two-line LDS window
     static_assert(!GATHER || STAGE_WORDS >= (THREADS / 64) * 64 * VKMR_MAP_GATHER_STRIDE, "staging area must hold the gather rows");
+    static_assert(!LINEWIN || STAGE_WORDS >= THREADS * VKMR_MAP_WIN_STRIDE, "staging area must hold one window row per lane");
     __shared__ uint4 s_stage4[(VKMR_MAP_STAGE_WORDS + VKMR_MAP_STAGE_PAD) / 4];
     __shared__ uint2 s_meta[VKMR_MAP_MAX_TILE];
     __shared__ uint16_t s_order[VKMR_MAP_MAX_TILE];
@@ -210,10 +238,45 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
             for (int j = 0; j < 16; ++j) gstart[GATHER ? j : 0] = __shfl(start, 4 * j + (int)sub);
         }
 
+        // Line window (MODE 4): this lane's LDS row holds line m in words 0..31 and line m+1 in 32..63 while blocks 2m
+        // and 2m+1 are hashed; R carries the line after those, requested a pair of blocks before it is needed.
+        uint32_t* row = s_stage + tid * VKMR_MAP_WIN_STRIDE;
+        uint4* row4 = reinterpret_cast<uint4*>(row);
+        uint4 R[LINEWIN ? 8 : 1];
+        long long line0 = 0;       // word index of the string's first line
+        uint32_t lo = 0;           // the string's word offset inside that line
+        unsigned long long wend = 0;   // one past the string's last word
+        if (LINEWIN) {
+            const unsigned long long addr = reinterpret_cast<unsigned long long>(data) + 4ull * start;
+            lo = (uint32_t)(addr >> 2) & 31u;
+            line0 = (long long)start - (long long)lo;
+            wend = (unsigned long long)start + (((unsigned long long)size + 3ull) >> 2);
+            uint4 (&R8)[8] = reinterpret_cast<uint4 (&)[8]>(R);
+            load_line(data, data_words, line0, has && size != 0u, R8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) row4[q] = R8[q];
+            load_line(data, data_words, line0 + 32, has && (unsigned long long)(line0 + 32) < wend, R8);
+        }
+
         for (uint32_t b = 0; __any(b < nb); ++b) {
             uint32_t w[16];
             // raw words of this block (garbage beyond the string is masked below)
-            if (staged) {
+            if (LINEWIN) {
+                uint4 (&R8)[8] = reinterpret_cast<uint4 (&)[8]>(R);
+                if ((b & 1u) == 0u) {   // wave-uniform: a new pair of blocks begins
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) row4[8 + q] = R8[q];          // line m+1 joins line m in the window
+                    const long long next = line0 + 32ll * ((long long)(b >> 1) + 2ll);
+                    load_line(data, data_words, next, has && b < nb && (unsigned long long)next < wend, R8);   // line m+2, for the next pair
+                }
+                const uint32_t* src = row + lo + ((b & 1u) << 4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = src[i];
+                if ((b & 1u) != 0u) {   // the pair is done: line m+1 becomes the window's first line
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) row4[q] = row4[8 + q];
+                }
+            } else if (staged) {
                 uint32_t base = (uint32_t)(start - a0) + (b << 4);
                 base = base < span ? base : span;
 #pragma unroll

@@ -70,7 +70,7 @@ __attribute__((visibility("default"))) int vkmr_hip_debug_stamps(unsigned long l
 
 const char* vkmr_hip_kernel_info(void)
 {
-    return "map=map_kernel(tile-sorted by block count; LDS-staged tiles, per-lane dwordx4 for long strings) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
+    return "map=map_kernel(tile-sorted by block count; LDS-staged tiles for short strings, line-aligned per-lane loads through an LDS window for long ones) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
 }
 
 vkmr_status vkmr_hip_device_count(int* count)
@@ -309,14 +309,22 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
         case 2: launch_staged(map_kernel<256, 512, 8192, 0>, 256, 512, 8192); break;         // LDS-staged tiles, 32 KiB
         case 3: hipLaunchKernelGGL((map_kernel<256, 2048, 5120, 1, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev,
                                    count, out, tile); break;                                 // per-wavefront gather through LDS
-        case 4: launch_direct(avg_words >= 32); break;                                       // per-lane 16-byte loads for every length
+        case 4: launch_direct(avg_words >= 32); break;                                       // per-lane 16-byte loads for every length (round 1's long-string mode)
+        case 5: hipLaunchKernelGGL((map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words,
+                                   meta_dev, count, out, tile); break;                       // line-aligned loads through a per-lane LDS window
         default:
             // Shipped: short strings (< 128 B on average: a cache line holds several) go through
             // LDS-staged tiles -- HBM traffic == algorithmic bytes; the per-lane mode is 1-2 %
             // faster but re-reads lines that fell out of L2 (1.6x traffic, profiles/
-            // r01_map_fetch_modes.txt).  Long strings read per lane with the full-block fast path.
-            if (avg_words >= 32)
-                launch_direct(true);
+            // r01_map_fetch_modes.txt).
+            if (avg_words >= 32 && tile >= 1024u)
+                // long strings, full-size launch: whole 128-byte lines through a per-lane LDS window -- same time as
+                // the per-lane 16-byte loads (3.14 vs 3.15 ms on rndm * 4096), 1.06x instead of 1.46x the algorithmic
+                // HBM reads (profiles/r02_long_strings_line_window.txt)
+                hipLaunchKernelGGL((map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words,
+                                   meta_dev, count, out, tile);
+            else if (avg_words >= 32)
+                launch_direct(true);   // a short launch: smaller workgroups spread it over the chip
             else
                 launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384);
             break;
