@@ -8,7 +8,8 @@ import vk_merkle_roots_amd as vk  # noqa: E402
 
 dev = vk.HipDevice(0)
 log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 21
-b = vk.rndm_packed(42, 1 << log2, 4096)
+maxlen = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+b = vk.rndm_packed(42, 1 << log2, maxlen)
 d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * b.count)
 ev = [(dev.new_event(), dev.new_event()) for _ in range(5)]
 dev.map_async(d_data, b.words, d_meta, b.count, d_out)
@@ -20,4 +21,4 @@ for e0, e1 in ev:
 dev.sync()
 ms = [dev.elapsed_ms(e0, e1) for e0, e1 in ev]
 chk = int(dev.download(d_out, 32 * b.count).astype(np.uint64).sum())
-print({k: v for k, v in os.environ.items() if k.startswith("VKMR_MAP")}, "ms per launch", round(float(np.mean(ms)), 4), "min", round(min(ms), 4), "digest checksum", chk)
+print(f"2^{log2} x rndm {maxlen}", {k: v for k, v in os.environ.items() if k.startswith("VKMR_MAP")}, "ms per launch", round(float(np.mean(ms)), 4), "min", round(min(ms), 4), "digest checksum", chk)
