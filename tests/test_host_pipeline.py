@@ -16,7 +16,7 @@ from conftest import ROOT
 HOST = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc", "host")
 CSRC = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc")
 OUT = os.path.join(ROOT, "tests", "_build", "fake")
-LINE = re.compile(r"^(?P<name>\S+): computed root \(of (?P<items>\d+) item\(s\), (?P<bytes>\d+) byte\(s\)\) => (?P<root>[0-9a-f]*) in [0-9.e+-]+$")
+LINE = re.compile(r"^(?P<name>.+?): computed root \(of (?P<items>\d+) item\(s\), (?P<bytes>\d+) byte\(s\)\) => (?P<root>[0-9a-f]*) in [0-9.e+-]+$")
 SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
 
 
@@ -91,6 +91,17 @@ def test_hip_all_over_several_devices(fake_vkmr, native, golden, ndev, shape):
         r, out, m = run(fake_vkmr, "hip:all", stream_of(native, s), VKMR_FAKE_DEVICES=ndev, **shape)
         assert r.returncode == 0 and out[0] == "Initializing for: hip:all", r.stderr[-500:]
         assert m and (int(m["items"]), m["root"]) == (s["items"], s["root"]), (name, ndev, shape)
+
+
+def test_device_can_be_chosen_by_its_marketing_name(fake_vkmr, native, golden):
+    """The reference takes a Vulkan deviceName on the command line (Vkmr.cpp:69-96); a HIP marketing name works too."""
+    s = golden["streams"]["L7_three"]
+    r, out, m = run(fake_vkmr, "fake device 1", stream_of(native, s), VKMR_FAKE_DEVICES=3)
+    assert r.returncode == 0 and out[0] == "Initializing for: fake device 1" and m and m["root"] == s["root"]
+    r, out, m = run(fake_vkmr, "hip:7", b"a\n", VKMR_FAKE_DEVICES=3)
+    assert r.returncode == 1 and b"No device selected; aborting." in r.stderr
+    r, out, m = run(fake_vkmr, "hip:all", b"a\n", VKMR_FAKE_DEVICES=1)      # one device: no "hip:all"
+    assert r.returncode == 1
 
 
 def test_root_array_grows_past_its_first_capacity(fake_vkmr, native, oracle):

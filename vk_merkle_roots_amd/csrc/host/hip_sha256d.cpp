@@ -55,11 +55,26 @@ std::vector<ISha256D::name_type> HipSha256D::Available() const
     return names;
 }
 
+// The reference selects a GPU by its Vulkan deviceName (src/vkmr/SHA-256vk.cpp:219-229; .vscode/launch.json:12
+// hard-codes one).  Here devices are listed as "hip:<n>" (eight MI355X of a node share one marketing name), and a
+// marketing name is accepted as an alias of the first device that carries it.
+int HipSha256D::IndexOf(const ISha256D::name_type& name) const
+{
+    if (name.size() > 4 && name.compare(0, 4, "hip:") == 0 && name.find_first_not_of("0123456789", 4) == std::string::npos) {
+        const long i = atol(name.c_str() + 4);
+        return i < m_count ? (int)i : -1;
+    }
+    for (int i = 0; i < m_count; ++i) {
+        char devname[256] = "";
+        if (vkmr_hip_device_name(i, devname, sizeof devname) == VKMR_OK && name == devname) return i;
+    }
+    return -1;
+}
+
 bool HipSha256D::Has(const ISha256D::name_type& name) const
 {
-    for (const auto& n : Available())
-        if (n == name) return true;
-    return false;
+    if (name == "hip:all") return m_count > 1;
+    return IndexOf(name) >= 0;
 }
 
 std::unique_ptr<HipSha256D::Instance> HipSha256D::Get(const ISha256D::name_type& name, const HipConfig& cfg)
@@ -68,7 +83,7 @@ std::unique_ptr<HipSha256D::Instance> HipSha256D::Get(const ISha256D::name_type&
     if (name == "hip:all") {
         for (int i = 0; i < m_count; ++i) devs.push_back(i);
     } else {
-        devs.push_back(atoi(name.c_str() + 4));
+        devs.push_back(IndexOf(name));
     }
     return std::unique_ptr<Instance>(new Instance(name, devs, cfg));
 }

@@ -47,6 +47,7 @@ public:
     std::vector<ISha256D::name_type> Available() const;
 
 private:
+    int IndexOf(const ISha256D::name_type&) const;   // device index of "hip:<n>" or of a marketing name; -1 if none
     int m_count;
 };
 
