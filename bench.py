@@ -224,6 +224,43 @@ def pipeline_rate(dev, vk, batch, nbatches, bstr, cap, nslices, slice_height, tr
     return {"leaf_hashes_per_s": n / dt, "ms": dt * 1e3, "h2d_GBps": (batch.words * 4 + n * 8) / dt / 1e9, "root": final.copy()}
 
 
+def two_stream_rate(dev, vk, d_batch, bstr, n, slice_height, steps=8):
+    """The same work with the map on one stream and the reduction on another, as the stream processor runs them
+    (csrc/host/hip_sha256d.cpp: map_stream / reduce_stream per device): step k+1's map fills the chip while step k's
+    reduction is in its latency-bound top (0.3 ms of mostly idle GPU), and the host does not wait per step.  Two
+    digest buffers, events between the streams.  Reported beside `value`, which stays the one-stream figure."""
+    d_data, words, d_meta = d_batch
+    map_stream, red_stream = dev.new_stream(), dev.new_stream()
+    bufs = [dev.alloc(32 * n) for _ in range(2)]
+    scratch = [dev.alloc(dev.lib.vkmr_hip_reduce_scratch_bytes(n)) for _ in range(2)]
+    d_roots = dev.alloc(32 * (steps + 1))
+    mapped = [dev.new_event() for _ in range(2)]
+    reduced = [dev.new_event() for _ in range(2)]
+
+    def run(k_steps):
+        for k in range(k_steps):
+            z = k & 1
+            if k >= 2:   # the digest buffer is free once the reduction that read it has finished
+                vk.check(dev.lib.vkmr_hip_stream_wait_event(dev.index, map_stream, reduced[z]), "wait")
+            dev.map_async(d_data, words, d_meta, bstr, bufs[z], stream=map_stream)
+            dev.record(mapped[z], map_stream)
+            vk.check(dev.lib.vkmr_hip_stream_wait_event(dev.index, red_stream, mapped[z]), "wait")
+            vk.check(dev.lib.vkmr_hip_reduce_async(dev.index, red_stream, bufs[z].ptr, n, slice_height, scratch[z].ptr, d_roots.at(32 * k)), "reduce")
+            dev.record(reduced[z], red_stream)
+        dev.sync(map_stream)
+        dev.sync(red_stream)
+
+    run(2)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    roots = dev.download(d_roots, 32 * steps).reshape(-1, 8)
+    for b in bufs + scratch + [d_roots]:
+        b.free()
+    return {"leaf_hashes_per_s": n / dt, "ms_per_step": dt * 1e3, "roots": roots,
+            "what": "map on one stream, reduction on another, two digest buffers, no host wait per step"}
+
+
 def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=5):
     """BASELINE configs[4]'s shape on the map kernel: rndm <seed> 2^21 4096 (lengths 1..4095, 1..65 blocks per
     string) as ONE batch of about 4.3 GB -- the size a long-string batch needs to fill the chip."""
@@ -538,6 +575,10 @@ def main():
             out["pipeline_pcie_inclusive"] = {"leaf_hashes_per_s": pl["leaf_hashes_per_s"], "ms": pl["ms"], "h2d_GBps": pl["h2d_GBps"],
                                               "root_matches": digest_hex(pl["root"]) == root_hex,
                                               "what": "pinned host batches -> async H2D overlapped with map -> reduce -> root"}
+        if world == 1 and not a.no_pipeline and not a.levels_variant and nbatches == 1 and nslices == 1:
+            ts = two_stream_rate(dev, vk, d_batches[0], bstr, n, slice_height)
+            out["two_stream_overlap"] = {"leaf_hashes_per_s": ts["leaf_hashes_per_s"], "ms_per_step": ts["ms_per_step"], "what": ts["what"],
+                                         "roots_match": all(digest_hex(r) == root_hex for r in ts["roots"])}
         if world == 1 and not a.no_long_strings:
             for b_ in d_batches:
                 b_[0].free()

@@ -79,3 +79,17 @@ def _leaves(oracle, seed, n):
     import vk_merkle_roots_amd as vk
     b = vk.rndm_packed(seed, n, 127)
     return oracle.leaves_packed(b.data, b.meta, threads=4)
+
+
+def test_bench_secondary_blocks_agree_with_the_timed_root(fake_lib, oracle):
+    """pipeline_pcie_inclusive (pinned host batches, copy stream) and two_stream_overlap (map and reduce streams, two
+    digest buffers) are separate drivings of the same ABI: each must reproduce the timed path's root."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["VKMR_HIP_LIB"] = fake_lib
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--leaves-log2", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-long-strings"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:].decode()
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["root"] == oracle.hex(oracle_root(oracle, 42, 1 << 12))
+    assert d["pipeline_pcie_inclusive"]["root_matches"] is True
+    assert d["two_stream_overlap"]["roots_match"] is True
