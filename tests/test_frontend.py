@@ -266,3 +266,24 @@ def test_very_long_lines_pipe_and_mapped_file(native, oracle, tmp_path):
     with open(path, "rb") as f:
         r = subprocess.run([tool(native, "vkmr"), "CPU"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert want in r.stdout.decode() and f"(of {cnt} item(s), {nb} byte(s))" in r.stdout.decode()
+
+
+@pytest.mark.gpu
+def test_config3_from_stdin_matches_the_reference_cpu_path(native, tmp_path):
+    """BASELINE configs[2] end to end, as the north star words it: `rndm 42 67108864 127 | vkmr hip:0` prints the root,
+    the item count and the byte count that the reference's own CPU-serial path printed for the same stream
+    (tests/golden/big_roots.json, made by oracle/_ref/rndm | oracle/_ref/vkmr_cpu_ref: four minutes there, a second here)."""
+    import json
+    from conftest import ROOT
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "big_roots.json")))
+    want = big["sub_roots"]["42"]
+    path = tmp_path / "g26.txt"
+    with open(path, "wb") as f:
+        subprocess.check_call([tool(native, "rndm"), "42", str(big["count"]), str(big["maxlen"])], stdout=f, stderr=subprocess.DEVNULL)
+    for env in ({}, {"VKMR_SLICE_LOG2": "26"}):     # eight slices of 2^23 (the reference's slice), and one slice
+        e = dict(os.environ, **env)
+        with open(path, "rb") as f:
+            r = subprocess.run([tool(native, "vkmr"), "hip:0"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=900)
+        m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
+        assert (int(m["items"]), int(m["bytes"]), m["root"]) == (want["items"], want["bytes"], want["root"]), env
+    os.unlink(path)
