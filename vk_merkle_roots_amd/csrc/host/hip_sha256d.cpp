@@ -71,6 +71,15 @@ int HipSha256D::IndexOf(const ISha256D::name_type& name) const
     return -1;
 }
 
+std::string HipSha256D::Describe(const ISha256D::name_type& name) const
+{
+    if (name.compare(0, 4, "hip:") != 0 || name == "hip:all") return name == "hip:all" ? " (slices dealt over every GPU)" : "";
+    char devname[256] = "";
+    const int i = IndexOf(name);
+    if (i < 0 || vkmr_hip_device_name(i, devname, sizeof devname) != VKMR_OK || !devname[0]) return "";
+    return std::string(" (\"") + devname + "\")";
+}
+
 bool HipSha256D::Has(const ISha256D::name_type& name) const
 {
     if (name == "hip:all") return m_count > 1;

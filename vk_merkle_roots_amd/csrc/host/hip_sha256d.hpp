@@ -45,6 +45,8 @@ public:
     // One use per name, like the reference's Get (SHA-256vk.cpp:224-229).
     std::unique_ptr<Instance> Get(const ISha256D::name_type&, const HipConfig& cfg = HipConfig::FromEnv());
     std::vector<ISha256D::name_type> Available() const;
+    // " (<marketing name>)" for a "hip:<n>" entry -- the name the reference would have listed -- else "".
+    std::string Describe(const ISha256D::name_type&) const;
 
 private:
     int IndexOf(const ISha256D::name_type&) const;   // device index of "hip:<n>" or of a marketing name; -1 if none

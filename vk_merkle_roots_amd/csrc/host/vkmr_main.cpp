@@ -59,7 +59,7 @@ int main(int argc, const char* argv[])
         } else {
             std::cerr << "Usage: " << argv[0] << " <name of compute device>" << std::endl;
             std::cerr << "Available: " << std::endl;
-            for (const auto& name : available) std::cerr << "* " << name << std::endl;
+            for (const auto& name : available) std::cerr << "* " << name << gpus.Describe(name) << std::endl;
             return 1;
         }
     }
