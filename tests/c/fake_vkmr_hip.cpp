@@ -357,9 +357,32 @@ vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_dige
     return VKMR_OK;
 }
 
-vkmr_status vkmr_hip_proof_async(int, vkmr_stream, const vkmr_digest*, uint64_t, uint32_t, uint64_t, void*, vkmr_digest*, vkmr_digest*)
+vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream, const vkmr_digest* digests, uint64_t count, uint32_t height, uint64_t index, void* scratch,
+                                 vkmr_digest* siblings, vkmr_digest* root)
 {
-    return fail(VKMR_ERR_INVALID, "proof: not provided by the fake ABI");
+    if (!dev_ok(dev) || !digests || !siblings || count == 0 || height > 63 || vkmr_plan::ceil_shift(count, height) != 1 || index >= count)
+        return fail(VKMR_ERR_INVALID, "proof: bad argument");
+    if (room_at(digests) < count * 32 || (height && room_at(siblings) < (size_t)height * 32)) return fail(VKMR_ERR_INVALID, "proof: not device memory");
+    if (count > 128 && room_at(scratch) < 64) return fail(VKMR_ERR_INVALID, "proof: null scratch");
+    std::vector<uint32_t> nodes(8 * count);   // level by level, the sibling of the path node picked at each
+    memcpy(nodes.data(), digests, 32 * count);
+    uint64_t n = count, p = index;
+    for (uint32_t lv = 0; lv < height; ++lv) {
+        const uint64_t q = ((p ^ 1ull) < n) ? (p ^ 1ull) : p;
+        memcpy(siblings[lv].data, nodes.data() + 8 * q, 32);
+        const uint64_t pairs = (n + 1) / 2;
+        for (uint64_t k = 0; k < pairs; ++k) {
+            const uint32_t* l = nodes.data() + 16 * k;
+            const uint32_t* r = (2 * k + 1 < n) ? l + 8 : l;
+            uint32_t h[8];
+            vkmr::cpu_sha256d_pair(l, r, h);
+            memcpy(nodes.data() + 8 * k, h, 32);
+        }
+        n = pairs;
+        p >>= 1;
+    }
+    if (root) memcpy(root->data, nodes.data(), 32);
+    return VKMR_OK;
 }
 
 vkmr_status vkmr_hip_comm_create_id(void* id)

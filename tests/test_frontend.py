@@ -287,3 +287,34 @@ def test_config3_from_stdin_matches_the_reference_cpu_path(native, tmp_path):
         m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
         assert (int(m["items"]), int(m["bytes"]), m["root"]) == (want["items"], want["bytes"], want["root"]), env
     os.unlink(path)
+
+
+def _fold_proof(lines):
+    d = lambda b: hashlib.sha256(hashlib.sha256(b).digest()).digest()
+    cur = bytes.fromhex(lines[0].split()[-1])
+    for l in lines[1:]:
+        _, _, level, side, hexsib = l.split()
+        cur = d(bytes.fromhex(hexsib) + cur) if side == "sibling-on-left" else d(cur + bytes.fromhex(hexsib))
+    return cur.hex()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"VKMR_SLICE_LOG2": "16"}, {"VKMR_SLICE_LOG2": "13", "VKMR_SLICE_BUDGET": "2"}, {"VKMR_SLICE_LOG2": "17", "_ndev": "4"}])
+def test_hip_merkle_proof_folds_to_the_root(native, golden, env):
+    """VKMR_PROOF_INDEX on the GPU (the reference's to-do, README.md:118-120): siblings inside the leaf's slice come from
+    vkmr_hip_proof_async on the reduction's stream, those above from a proof over the slice roots; folding them with
+    hashlib gives the root of the same run, which is the golden one."""
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    stream = golden_stream(native, s)
+    leaves = [l for l in stream.split(b"\n") if l]
+    env = dict(env)
+    ndev = int(env.pop("_ndev", "1"))
+    if ndev > 1:
+        env.update(virtual_devices_env(ndev))
+    for index in (0, 65535, 65536, 700001, 1048575):
+        r, out, m = run_vkmr(native, "hip:all" if ndev > 1 else "hip:0", stream, dict(env, VKMR_PROOF_INDEX=str(index)))
+        assert m and m["root"] == s["root"], (index, env, r.stderr[-300:])
+        proof = [l for l in out if l.startswith("proof: ")]
+        assert proof and proof[0].split()[2] == str(index)
+        assert proof[0].split()[-1] == hashlib.sha256(hashlib.sha256(leaves[index]).digest()).digest().hex()
+        assert _fold_proof(proof) == s["root"], (index, env)

@@ -203,3 +203,41 @@ def test_parallel_packer_in_the_pipeline_under_tsan(native, golden, tmp_path):
     assert b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:].decode()
     m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
     assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])
+
+
+def fold_proof(lines):
+    """Folds "proof: ..." lines (leaf digest, then one sibling per level with its side) into a root, with hashlib."""
+    import hashlib
+    d = lambda b: hashlib.sha256(hashlib.sha256(b).digest()).digest()
+    cur = bytes.fromhex(lines[0].split()[-1])
+    for l in lines[1:]:
+        _, _, level, side, hexsib = l.split()
+        sib = bytes.fromhex(hexsib)
+        cur = d(sib + cur) if side == "sibling-on-left" else d(cur + sib)
+    return cur.hex()
+
+
+@pytest.mark.parametrize("ndev,shape", [(1, {}), (1, {"VKMR_SLICE_LOG2": 6}), (1, {"VKMR_SLICE_LOG2": 4, "VKMR_SLICE_BUDGET": 1}), (3, {"VKMR_SLICE_LOG2": 5}),
+                                        (8, {"VKMR_SLICE_LOG2": 3})])
+def test_merkle_proof_of_a_leaf_folds_to_the_printed_root(fake_vkmr, native, golden, oracle, ndev, shape):
+    """VKMR_PROOF_INDEX (the reference's to-do, README.md:118-120): the leaf's digest and one sibling per level -- inside
+    the leaf's slice, then over the slice roots -- fold to the root the same run prints, for first, last, middle and
+    ragged-edge leaves, one or several devices."""
+    s = golden["streams"]["G6_rndm_7_1000_300"]
+    stream = stream_of(native, s)
+    lines_in = [l for l in stream.split(b"\n") if l]
+    for index in (0, 1, 511, 512, 640, 998, 999):
+        r, out, m = run(fake_vkmr, "hip:all" if ndev > 1 else "hip:0", stream, VKMR_FAKE_DEVICES=ndev, VKMR_PROOF_INDEX=index, **shape)
+        assert m and m["root"] == s["root"], (index, shape)
+        proof = [l for l in out if l.startswith("proof: ")]
+        assert proof[0].split()[:3] == ["proof:", "leaf", str(index)], proof[:2]
+        assert proof[0].split()[-1] == oracle.hex(oracle.leaf(lines_in[index])), index
+        assert fold_proof(proof) == s["root"], (index, ndev, shape)
+    r, out, m = run(fake_vkmr, "hip:0", stream, VKMR_PROOF_INDEX=1000, **shape)      # one past the last leaf
+    assert m["root"] == s["root"] and any("is not in the stream" in l for l in out)
+
+
+def test_merkle_proof_of_a_lone_leaf(fake_vkmr):
+    r, out, m = run(fake_vkmr, "hip:0", b"solo\n", VKMR_PROOF_INDEX=0)
+    proof = [l for l in out if l.startswith("proof: ")]
+    assert len(proof) == 2 and fold_proof(proof) == m["root"]      # a lone leaf is hashed with itself: one level

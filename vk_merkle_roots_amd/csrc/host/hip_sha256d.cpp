@@ -25,6 +25,7 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_MAX_INFLIGHT")) c.max_inflight = (size_t)atol(e);
     if (const char* e = getenv("VKMR_SLICE_BUDGET")) c.slice_budget = (size_t)atol(e);
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
+    if (const char* e = getenv("VKMR_PROOF_INDEX")) c.proof_index = atoll(e);
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -123,6 +124,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
     m_reductions = Reductions::New(devices, (size_t)1 << cfg.slice_log2, cfg.verbose);
     if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
     if (!m_reductions->Ok()) m_ok = false;   // reported by Reductions::New
+    if (cfg.proof_index >= 0) m_reductions->RequestProof((uint64_t)cfg.proof_index);
 }
 
 HipSha256D::Instance::~Instance()

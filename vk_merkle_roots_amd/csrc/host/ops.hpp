@@ -69,6 +69,13 @@ public:
     // the hex root ("" on failure or when nothing was reduced).
     virtual ISha256D::out_type WaitFor() = 0;
 
+    // Merkle proof (the reference's to-do, README.md:118-120): asks for the authentication path of leaf
+    // `leaf_index` (0-based, stream order).  The siblings inside the leaf's slice are computed when that slice is
+    // reduced (vkmr_hip_proof_async on the reduction's stream, before the slice's memory is re-used), those above
+    // it over the slice roots at WaitFor().  ProofLines() then gives "proof: ..." lines, bottom level first.
+    virtual void RequestProof(uint64_t leaf_index) = 0;
+    virtual std::vector<std::string> ProofLines() const = 0;
+
     // devices: every device slices are dealt to, in dealing order; capacity: digests per slice.
     static std::unique_ptr<Reductions> New(std::vector<int> devices, size_t capacity, bool verbose);
 };

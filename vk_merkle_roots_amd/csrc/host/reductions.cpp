@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <iostream>
+#include <string>
 
 #include "cpu_sha256d.hpp"
 #include "ops.hpp"
@@ -74,6 +75,8 @@ public:
             vkmr_hip_host_free(d.roots_host);
         }
         if (m_comm) vkmr_hip_comm_destroy(m_comm);
+        if (m_proof_dev) vkmr_hip_device_free(m_proof_dev_device, m_proof_dev);
+        vkmr_hip_host_free(m_proof_host);
     }
 
     HipResult Reduce(slice_type&& slice, uint32_t height, vkmr_stream stream) override
@@ -100,6 +103,33 @@ public:
     size_t Allocations() const override { return m_allocations; }
     bool Ok() const override { return !m_failed; }
 
+    void RequestProof(uint64_t leaf_index) override
+    {
+        m_proof_wanted = true;
+        m_proof_leaf = leaf_index;
+    }
+
+    std::vector<std::string> ProofLines() const override
+    {
+        std::vector<std::string> lines;
+        if (!m_proof_wanted) return lines;
+        if (!m_proof_done) {
+            lines.push_back("proof: leaf " + std::to_string(m_proof_leaf) + " is not in the stream (or the run failed)");
+            return lines;
+        }
+        lines.push_back("proof: leaf " + std::to_string(m_proof_leaf) + " " + digest_words_to_hex(m_proof_leaf_digest.data));
+        // bit l of the node index tells on which side the path node sits at level l; inside the slice the node index is the
+        // leaf's offset, above it the slice's position
+        uint64_t idx = m_proof_offset;
+        for (size_t l = 0; l < m_proof_path.size(); ++l) {
+            if (l == m_proof_slice_levels) idx = m_proof_slice_pos;
+            const bool path_is_right = (idx >> (l < m_proof_slice_levels ? l : l - m_proof_slice_levels)) & 1ull;
+            lines.push_back("proof: level " + std::to_string(l) + (path_is_right ? " sibling-on-left " : " sibling-on-right ") +
+                            digest_words_to_hex(m_proof_path[l].data));
+        }
+        return lines;
+    }
+
     ISha256D::out_type WaitFor() override
     {
         Retire(true, 0);
@@ -110,7 +140,10 @@ public:
             std::cerr << "Reduced " << m_retired << " of " << m_last_number << " slice(s); no root." << std::endl;
             return "";
         }
-        if (m_dispatched == 1) return digest_words_to_hex(m_devs[0].roots_host[0].data);   // Reductions.cpp:692-701
+        if (m_dispatched == 1) {   // Reductions.cpp:692-701
+            FinishProof(nullptr, 0);
+            return digest_words_to_hex(m_devs[0].roots_host[0].data);
+        }
         vkmr_digest top;
         if (Combine(&top) != VKMR_OK) {
             std::cerr << "Failed to combine the slice roots: " << vkmr_hip_last_error() << std::endl;
@@ -200,6 +233,32 @@ private:
         return st;
     }
 
+    // The part of the proof that lies inside the leaf's slice: `height` siblings and the leaf digest, computed on the
+    // reduction's stream right before the reduction (same scratch: the stream serialises them) and copied to the host.
+    HipResult ProveInSlice(PerDevice& d, const slice_type& slice, uint32_t height, void* scratch, vkmr_stream stream)
+    {
+        m_proof_slice_seen = true;
+        m_proof_offset = m_proof_leaf % m_capacity;
+        if (m_proof_offset >= slice.Count()) return VKMR_OK;   // past the end of the stream: reported by ProofLines()
+        m_proof_slice_levels = height;
+        m_proof_slice_number = slice.Number();
+        void* sib = nullptr;
+        HipResult st = vkmr_hip_device_alloc(d.dev, (size_t)(height + 1) * sizeof(vkmr_digest), &sib);
+        if (st == VKMR_OK && !m_proof_host) {
+            void* h = nullptr;
+            st = vkmr_hip_host_alloc(130 * sizeof(vkmr_digest), &h);   // leaf + up to 64 levels in the slice + 64 above it
+            m_proof_host = static_cast<vkmr_digest*>(h);
+        }
+        if (st == VKMR_OK)
+            st = vkmr_hip_proof_async(d.dev, stream, slice.Cells(), slice.Count(), height, m_proof_offset, scratch, static_cast<vkmr_digest*>(sib), nullptr);
+        if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, m_proof_host, slice.Cells() + m_proof_offset, sizeof(vkmr_digest));
+        if (st == VKMR_OK && height) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, m_proof_host + 1, sib, (size_t)height * sizeof(vkmr_digest));
+        m_proof_dev = sib;
+        m_proof_dev_device = d.dev;
+        m_proof_dispatched = (st == VKMR_OK);
+        return st;
+    }
+
     HipResult Dispatch(slice_type& slice, uint32_t height, vkmr_stream stream)
     {
         size_t di = 0;
@@ -214,6 +273,8 @@ private:
         if (st == VKMR_OK) st = Acquire(di, &r.res);
         if (st != VKMR_OK) return st;
         st = vkmr_hip_event_record(d.dev, r.res.begin, stream);
+        if (st == VKMR_OK && m_proof_wanted && !m_proof_slice_seen && slice.Number() == m_proof_leaf / m_capacity + 1)
+            st = ProveInSlice(d, slice, height, r.res.scratch, stream);
         if (st == VKMR_OK) st = vkmr_hip_reduce_async(d.dev, stream, slice.Cells(), slice.Count(), height, r.res.scratch, d.roots_dev + r.slot);
         if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, d.roots_host + r.slot, d.roots_dev + r.slot, sizeof(vkmr_digest));
         if (st == VKMR_OK) st = vkmr_hip_event_record(d.dev, r.res.done, stream);
@@ -255,6 +316,17 @@ private:
             d.spare.push_back(it->res);
             it = m_inflight.erase(it);   // the slice's memory returns to its pool here
         }
+    }
+
+    // Everything of the proof has reached the host (the streams were synchronised): assemble the path.
+    void FinishProof(const vkmr_digest* upper, uint32_t upper_levels)
+    {
+        if (!m_proof_dispatched || !m_proof_host || m_failed) return;
+        m_proof_leaf_digest = m_proof_host[0];
+        m_proof_path.assign(m_proof_host + 1, m_proof_host + 1 + m_proof_slice_levels);
+        for (uint32_t l = 0; l < upper_levels; ++l) m_proof_path.push_back(upper[l]);
+        m_proof_slice_pos = m_proof_slice_number - 1;
+        m_proof_done = true;
     }
 
     // Root over all slice roots, in slice order, on the first device.
@@ -300,12 +372,26 @@ private:
         if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, vkmr_hip_reduce_scratch_bytes(total), &scratch);
         if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, sizeof(vkmr_digest), &final_dev);
         if (st == VKMR_OK) st = vkmr_hip_host_alloc(sizeof(vkmr_digest), &final_host);
+        // the proof's upper part: the path of the leaf's slice among the slice roots (same tree as the combine)
+        void* up_sib = nullptr;
+        uint32_t up_levels = 0;
+        if (st == VKMR_OK && m_proof_dispatched) {
+            up_levels = 1;
+            while (((uint64_t)total + ((1ull << up_levels) - 1ull)) >> up_levels > 1) ++up_levels;
+            st = vkmr_hip_device_alloc(d0.dev, (size_t)up_levels * sizeof(vkmr_digest), &up_sib);
+            if (st == VKMR_OK)
+                st = vkmr_hip_proof_async(d0.dev, d0.stream, roots, total, up_levels, m_proof_slice_number - 1, scratch, static_cast<vkmr_digest*>(up_sib), nullptr);
+            if (st == VKMR_OK)
+                st = vkmr_hip_memcpy_d2h_async(d0.dev, d0.stream, m_proof_host + 1 + m_proof_slice_levels, up_sib, (size_t)up_levels * sizeof(vkmr_digest));
+        }
         if (st == VKMR_OK) st = vkmr_hip_combine_async(d0.dev, d0.stream, roots, total, scratch, static_cast<vkmr_digest*>(final_dev));
         if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d0.dev, d0.stream, final_host, final_dev, sizeof(vkmr_digest));
         if (st == VKMR_OK) st = vkmr_hip_stream_sync(d0.dev, d0.stream);
         for (size_t i = 1; i < ndev && st == VKMR_OK; ++i)   // the other ranks' side of the gather
             if (m_devs[i].stream && gathered[i]) st = vkmr_hip_stream_sync(m_devs[i].dev, m_devs[i].stream);
         if (st == VKMR_OK) std::memcpy(top, final_host, sizeof(vkmr_digest));
+        if (st == VKMR_OK) FinishProof(m_proof_host ? m_proof_host + 1 + m_proof_slice_levels : nullptr, up_levels);
+        vkmr_hip_device_free(d0.dev, up_sib);
         for (size_t i = 0; i < ndev; ++i) vkmr_hip_device_free(m_devs[i].dev, gathered[i]);
         vkmr_hip_device_free(d0.dev, ordered);
         vkmr_hip_device_free(d0.dev, scratch);
@@ -327,6 +413,15 @@ private:
     std::vector<Reduction> m_inflight;
     std::vector<size_t> m_own_streams;
     vkmr_comm m_comm = nullptr;
+    // the requested Merkle proof (at most one per run)
+    bool m_proof_wanted = false, m_proof_slice_seen = false, m_proof_dispatched = false, m_proof_done = false;
+    uint64_t m_proof_leaf = 0, m_proof_offset = 0, m_proof_slice_pos = 0;
+    uint32_t m_proof_slice_levels = 0, m_proof_slice_number = 0;
+    vkmr_digest* m_proof_host = nullptr;   // pinned: leaf digest, siblings inside the slice, siblings above it
+    void* m_proof_dev = nullptr;
+    int m_proof_dev_device = -1;
+    vkmr_digest m_proof_leaf_digest{};
+    std::vector<vkmr_digest> m_proof_path;
 };
 
 }  // namespace

@@ -40,6 +40,9 @@ static int run(vkmr::ISha256D& backend)
         const double elapsed = sw.Elapsed();
         std::cout << backend.Name() << ": computed root (of " << count << " item(s), " << size << " byte(s)) => " << root
                   << " in " << elapsed << std::endl;
+        // the Merkle proof of one leaf, when asked for (VKMR_PROOF_INDEX; the reference's to-do, README.md:118-120)
+        if (auto* hip = dynamic_cast<vkmr::HipSha256D::Instance*>(&backend))
+            for (const auto& l : hip->ProofLines()) std::cout << l << std::endl;
     }
     return 0;
 }
