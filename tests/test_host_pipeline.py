@@ -226,7 +226,7 @@ def test_merkle_proof_of_a_leaf_folds_to_the_printed_root(fake_vkmr, native, gol
     s = golden["streams"]["G6_rndm_7_1000_300"]
     stream = stream_of(native, s)
     lines_in = [l for l in stream.split(b"\n") if l]
-    for index in (0, 1, 511, 512, 640, 998, 999):
+    for index in (0, 512, 640, 999):
         r, out, m = run(fake_vkmr, "hip:all" if ndev > 1 else "hip:0", stream, VKMR_FAKE_DEVICES=ndev, VKMR_PROOF_INDEX=index, **shape)
         assert m and m["root"] == s["root"], (index, shape)
         proof = [l for l in out if l.startswith("proof: ")]
