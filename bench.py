@@ -296,6 +296,43 @@ def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=5):
             "valu_achieved_tops": ops / (ms * 1e-3) / 1e12, "compressions_per_string": blocks / n + 1}
 
 
+def hip_all_check(timeout_s=120):
+    """On a multi-GPU node: the C++ front end's one-process path, `rndm 42 2^20 127 | vkmr hip:all` with slices of
+    2^17 -- eight slices dealt over the node's GPUs, ONE RCCL all-gather of their roots inside that process
+    (vkmr_hip_comm_init_all + vkmr_hip_gather_roots_async), combine on GPU 0 -- against the golden root of that stream
+    (tests/golden/vectors.json, printed by the reference's CPU path).  A correctness probe run by rank 0 after the
+    timed region; a failure is reported in the field, it does not change `value`."""
+    vkmr = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "vkmr")
+    rndm = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "rndm")
+    try:
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", "vectors.json")))["streams"]["G3_rndm_42_1048576_127"]["root"]
+        import tempfile
+        with tempfile.NamedTemporaryFile(prefix="vkmr_g3_", suffix=".txt") as tmp:   # a file, not a pipe: nothing can block on a full pipe
+            subprocess.run([rndm, "42", "1048576", "127"], stdout=tmp, stderr=subprocess.DEVNULL, check=True, timeout=timeout_s)
+            tmp.flush()
+            env = dict(os.environ, VKMR_SLICE_LOG2="17")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VKMR_HIP_LIB"):
+                env.pop(k, None)
+            t0 = time.perf_counter()
+            with open(tmp.name, "rb") as f:
+                child = subprocess.Popen([vkmr, "hip:all"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                try:
+                    so, se = child.communicate(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    child.kill()
+                    child.communicate()
+                    return {"ran": True, "root_matches_golden": False, "error": f"no answer within {timeout_s} s"}
+        line = [l for l in so.decode().splitlines() if "computed root" in l]
+        if child.returncode != 0 or not line:
+            return {"ran": child.returncode == 0, "root_matches_golden": None if b"No device selected" in se else False,
+                    "error": (se.decode().strip().splitlines() or ["no output"])[-1][:200]}
+        root = line[-1].split("=> ")[1].split(" in ")[0]
+        return {"ran": True, "what": "rndm 42 2^20 127 | vkmr hip:all, 8 slices of 2^17 dealt over the node's GPUs, one RCCL all-gather in one process",
+                "root_matches_golden": root == want, "root": root, "seconds": time.perf_counter() - t0}
+    except Exception as e:   # a probe must not take the bench line down with it
+        return {"ran": False, "root_matches_golden": None, "error": repr(e)[:200]}
+
+
 def golden_big_roots(leaves_log2, maxlen):
     path = os.path.join(ROOT, "tests", "golden", "big_roots.json")
     try:
@@ -587,6 +624,8 @@ def main():
             out["long_strings"] = long_strings_rate(dev, vk, a.seed)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.seed, a.maxlen, min(a.cpu_sample_log2, a.leaves_log2), a.leaves_log2)
+        if world > 1 and comm is not None:
+            out["hip_all_one_process_check"] = hip_all_check()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         dev.lib.vkmr_hip_comm_destroy(comm)
