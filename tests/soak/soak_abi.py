@@ -1,3 +1,5 @@
+"""Random streams through the C ABI with random slicings against the oracle (the oracle is the checker, so this lives
+under tests/).  GPU box only:  python3 tests/soak/soak_abi.py [seconds]  (run from the repo root)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, vk_merkle_roots_amd as vk

@@ -1,6 +1,6 @@
 """Random streams through the C++ front end (`vkmr hip:0`, and `vkmr hip:all` over an aliased GPU) with random
 pipeline shapes -- slice size, batch size, mappings in flight, slice budget -- against the oracle.  GPU box only.
-    python3 tools/soak_frontend.py [seconds]"""
+    python3 tests/soak/soak_frontend.py [seconds]"""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import Oracle, build_virt_devices  # noqa: E402
