@@ -76,3 +76,18 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"liboracle|oracle_|oracle/|_ref/|hashlib", t):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_product_does_not_reference_the_test_doubles():
+    """tests/c/fake_vkmr_hip.cpp (host memory + CPU hashing behind the C ABI) and tests/c/virt_devices.cpp (one GPU shown
+    as several) exist for the test suites only: nothing the product ships may name or load them."""
+    bad = []
+    for base in ("vk_merkle_roots_amd", "include", "bench.py", "__graft_entry__.py"):
+        path = os.path.join(ROOT, base)
+        files = [path] if os.path.isfile(path) else [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs
+                                                     if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".c"))]
+        for f in files:
+            t = open(f, errors="replace").read()
+            if re.search(r"fake_vkmr|virt_devices|tests/_build|VKMR_FAKE_|VKMR_TEST_VIRTUAL", t):
+                bad.append(f)
+    assert not bad, bad
