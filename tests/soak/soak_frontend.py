@@ -20,7 +20,7 @@ virt = build_virt_devices()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(int(time.time()))
 t0 = time.time()
-cases = 0
+cases = proofs = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.integers(1, 3000), rng.integers(1, 300000)]))
     maxlen = int(rng.choice([2, 20, 65, 127, 300, 3000]))
@@ -35,10 +35,24 @@ while time.time() - t0 < budget:
     if rng.integers(0, 3) == 0:
         env.update(LD_PRELOAD=virt, VKMR_TEST_VIRTUAL_DEVICES=str(int(rng.integers(2, 9))))
         backend = "hip:all"
+    proof_index = int(rng.integers(0, cnt)) if cnt and rng.integers(0, 3) == 0 else None
+    if proof_index is not None:
+        env["VKMR_PROOF_INDEX"] = str(proof_index)
     r = subprocess.run([vkmr, backend], input=stream, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
     line = [l for l in r.stdout.decode().splitlines() if "computed root" in l]
     shape = {k: v for k, v in env.items() if k.startswith("VKMR_")}
     assert r.returncode == 0 and line, (seed, n, maxlen, backend, shape, r.stderr[-300:])
     assert f"(of {cnt} item(s), {nb} byte(s)) => {want} in" in line[-1], (seed, n, maxlen, backend, shape, line[-1])
+    if proof_index is not None:   # the printed Merkle proof folds to the printed root
+        import hashlib
+        d = lambda b: hashlib.sha256(hashlib.sha256(b).digest()).digest()
+        pl = [l for l in r.stdout.decode().splitlines() if l.startswith("proof: ")]
+        assert pl and pl[0].split()[2] == str(proof_index), (seed, n, proof_index, pl[:1])
+        cur = bytes.fromhex(pl[0].split()[-1])
+        for l in pl[1:]:
+            side, sib = l.split()[3], bytes.fromhex(l.split()[4])
+            cur = d(sib + cur) if side == "sibling-on-left" else d(cur + sib)
+        assert cur.hex() == want, (seed, n, maxlen, backend, shape, proof_index)
+        proofs += 1
     cases += 1
-print("front-end soak ok:", cases, "random streams and pipeline shapes, all roots equal the oracle")
+print("front-end soak ok:", cases, "random streams and pipeline shapes, all roots equal the oracle;", proofs, "random Merkle proofs fold to their root")
