@@ -513,6 +513,7 @@ vkmr_status vkmr_hip_reduce_levels_async(int dev, vkmr_stream s, const vkmr_dige
         const uint64_t pairs = ceil_shift(n, 1);
         Node* out = (lv + 1 == height) ? reinterpret_cast<Node*>(root_dev) : ((lv & 1) ? bufB : bufA);
         const uint64_t grid = (pairs + 255) / 256;
+        if (grid > 0x7fffffffull) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_levels_async: slice too large");
         hipLaunchKernelGGL(reduce_level_kernel, dim3((uint32_t)grid), dim3(256), 0, S(s), in, n, out);
         VKMR_TRY(hipGetLastError());
         in = out;
