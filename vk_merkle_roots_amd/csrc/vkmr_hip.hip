@@ -274,11 +274,15 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
     Node* out = reinterpret_cast<Node*>(out_dev);
-    // staged mode: strings per tile = what is expected to fit the LDS staging area
+    // staged mode: strings per tile = what is expected to fit the LDS staging area.  95 % of it (896 strings for rndm * 127:
+    // 58 of 64 KiB, six standard deviations of a tile's size below the limit) -- the more strings a tile sorts, the fewer
+    // of its groups straddle a block-count boundary: 6.70 ms per 2^26 strings against 6.78 at 90 % (832 strings), and
+    // no better at 100 % (960), where the tiles that overflow fall back to per-lane loads (profiles/r02_map_tile_fill.txt)
     auto launch_staged = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
         uint32_t tile = max_tile;
         if (avg_words > 0) {
-            const uint64_t fit = (uint64_t)(stage_words * 0.9) / avg_words;
+            static const int fit_pct = [] { const char* e = getenv("VKMR_MAP_FIT"); const int v = e ? atoi(e) : 95; return (v < 50 || v > 100) ? 95 : v; }();   // experiments only
+            const uint64_t fit = (uint64_t)stage_words * (uint64_t)fit_pct / 100u / avg_words;
             if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
         }
         hipLaunchKernelGGL(kern, dim3((uint32_t)(((uint64_t)count + tile - 1) / tile)), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
