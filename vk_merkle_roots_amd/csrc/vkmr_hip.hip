@@ -274,15 +274,20 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
     Node* out = reinterpret_cast<Node*>(out_dev);
-    // staged mode: strings per tile = what is expected to fit the LDS staging area.  95 % of it (896 strings for rndm * 127:
-    // 58 of 64 KiB, six standard deviations of a tile's size below the limit) -- the more strings a tile sorts, the fewer
-    // of its groups straddle a block-count boundary: 6.70 ms per 2^26 strings against 6.78 at 90 % (832 strings), and
-    // no better at 100 % (960), where the tiles that overflow fall back to per-lane loads (profiles/r02_map_tile_fill.txt)
+    // staged mode: strings per tile = what is expected to fit the LDS staging area, three standard deviations of a
+    // tile's size below it (string lengths spread like rndm's, uniform in [1, max]: sigma / mean of T strings is about
+    // 0.6 / sqrt(T)); a tile that overflows anyway falls back to per-lane loads.  The more strings a tile sorts the
+    // better: fewer of its groups straddle a block-count boundary, and 1024 strings are exactly two groups of 64 for
+    // each of the 8 wavefronts (896 strings leave two of them idle for half of the tile): 6.56 ms per 2^26 strings of
+    // rndm * 127 with 69 KiB / 1024 strings against 6.58 (68 KiB / 960), 6.70 (64 KiB / 896) and 6.78 (64 KiB / 832,
+    // round 1's shape) -- profiles/r02_map_tile_fill.txt.  69 KiB is what still lets two workgroups share a CU's LDS.
     auto launch_staged = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
         uint32_t tile = max_tile;
-        if (avg_words > 0) {
-            static const int fit_pct = [] { const char* e = getenv("VKMR_MAP_FIT"); const int v = e ? atoi(e) : 95; return (v < 50 || v > 100) ? 95 : v; }();   // experiments only
-            const uint64_t fit = (uint64_t)stage_words * (uint64_t)fit_pct / 100u / avg_words;
+        if (data_words > 0) {
+            static const int fit_pct = [] { const char* e = getenv("VKMR_MAP_FIT"); const int v = e ? atoi(e) : 0; return (v < 50 || v > 100) ? 0 : v; }();   // experiments only
+            const double r = (double)stage_words * (double)count / (double)data_words;   // strings that fill the area on average
+            const double want = fit_pct ? r * fit_pct / 100.0 : r * (1.0 - 1.8 / __builtin_sqrt(r > 4.0 ? r : 4.0));
+            const uint64_t fit = want > 0.0 ? (uint64_t)want : 0;
             if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
         }
         hipLaunchKernelGGL(kern, dim3((uint32_t)(((uint64_t)count + tile - 1) / tile)), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
@@ -309,11 +314,14 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
         }
     };
     switch (variant) {
-        case 1: launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384); break;     // LDS-staged tiles, 64 KiB
+        case 1: launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384); break;     // LDS-staged tiles, 64 KiB (round 1's shipped shape)
         case 2: launch_staged(map_kernel<256, 512, 8192, 0>, 256, 512, 8192); break;         // LDS-staged tiles, 32 KiB
         case 3: hipLaunchKernelGGL((map_kernel<256, 2048, 5120, 1, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev,
                                    count, out, tile); break;                                 // per-wavefront gather through LDS
         case 4: launch_direct(avg_words >= 32); break;                                       // per-lane 16-byte loads for every length (round 1's long-string mode)
+        case 6: launch_staged(map_kernel<512, 1024, 17408, 0>, 512, 1024, 17408); break;     // LDS-staged tiles, 68 KiB (two workgroups still fit a CU)
+        case 7: launch_staged(map_kernel<512, 1024, 17664, 0>, 512, 1024, 17664); break;     // LDS-staged tiles, 69 KiB
+        case 8: launch_staged(map_kernel<256, 1024, 17664, 0>, 256, 1024, 17664); break;     // the same tiles by 4 wavefronts instead of 8
         case 5: hipLaunchKernelGGL((map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words,
                                    meta_dev, count, out, tile); break;                       // line-aligned loads through a per-lane LDS window
         default:
@@ -330,7 +338,7 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
             else if (avg_words >= 32)
                 launch_direct(true);   // a short launch: smaller workgroups spread it over the chip
             else
-                launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384);
+                launch_staged(map_kernel<512, 1024, 17664, 0>, 512, 1024, 17664);
             break;
     }
     VKMR_TRY(hipGetLastError());
