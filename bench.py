@@ -261,15 +261,20 @@ def two_stream_rate(dev, vk, d_batch, bstr, n, slice_height, steps=8):
             "what": "map on one stream, reduction on another, two digest buffers, no host wait per step"}
 
 
-def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=5):
+def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=10):
     """BASELINE configs[4]'s shape on the map kernel: rndm <seed> 2^21 4096 (lengths 1..4095, 1..65 blocks per
     string) as ONE batch of about 4.3 GB -- the size a long-string batch needs to fill the chip."""
     n = 1 << count_log2
     b = vk.rndm_packed(seed, n, maxlen)
     d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * n)
     ev = [(dev.new_event(), dev.new_event()) for _ in range(launches)]
-    dev.map_async(d_data, b.words, d_meta, n, d_out)
-    dev.sync()
+    # the GPU has idled for the seconds the host took to generate this batch: warm up until it is back at its steady
+    # clocks (the first tens of milliseconds after idle run 10 % slower: profiles/r02_clock_power.txt)
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.4:
+        for _ in range(4):
+            dev.map_async(d_data, b.words, d_meta, n, d_out)
+        dev.sync()
     for e0, e1 in ev:
         dev.record(e0)
         dev.map_async(d_data, b.words, d_meta, n, d_out)

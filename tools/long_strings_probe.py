@@ -11,9 +11,15 @@ log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 maxlen = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 b = vk.rndm_packed(42, 1 << log2, maxlen)
 d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * b.count)
-ev = [(dev.new_event(), dev.new_event()) for _ in range(5)]
-dev.map_async(d_data, b.words, d_meta, b.count, d_out)
-dev.sync()
+ev = [(dev.new_event(), dev.new_event()) for _ in range(10)]
+# warm up for half a second: after seconds of host-side generation the GPU is in a low-power state, and the first tens of
+# milliseconds run below the steady clocks (3.13 vs 2.83 ms per launch on rndm * 4096; profiles/r02_clock_power.txt)
+import time
+t0 = time.time()
+while time.time() - t0 < float(os.environ.get("VKMR_PROBE_WARM_S", "0.5")):
+    for _ in range(4):
+        dev.map_async(d_data, b.words, d_meta, b.count, d_out)
+    dev.sync()
 for e0, e1 in ev:
     dev.record(e0)
     dev.map_async(d_data, b.words, d_meta, b.count, d_out)

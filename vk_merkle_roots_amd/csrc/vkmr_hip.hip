@@ -70,7 +70,7 @@ __attribute__((visibility("default"))) int vkmr_hip_debug_stamps(unsigned long l
 
 const char* vkmr_hip_kernel_info(void)
 {
-    return "map=map_kernel(tile-sorted by block count; LDS-staged tiles for short strings, line-aligned per-lane loads through an LDS window for long ones) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
+    return "map=map_kernel(tile-sorted by block count; LDS-staged tiles below 128 B on average, per-lane 16-byte loads up to 1 KiB, whole lines through a per-lane LDS window above) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
 }
 
 vkmr_status vkmr_hip_device_count(int* count)
@@ -329,14 +329,15 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
             // LDS-staged tiles -- HBM traffic == algorithmic bytes; the per-lane mode is 1-2 %
             // faster but re-reads lines that fell out of L2 (1.6x traffic, profiles/
             // r01_map_fetch_modes.txt).
-            if (avg_words >= 32 && tile >= 1024u)
-                // long strings, full-size launch: whole 128-byte lines through a per-lane LDS window -- same time as
-                // the per-lane 16-byte loads (3.14 vs 3.15 ms on rndm * 4096), 1.06x instead of 1.46x the algorithmic
-                // HBM reads (profiles/r02_long_strings_line_window.txt)
+            if (avg_words >= 256 && tile >= 1024u)
+                // very long strings (>= 1 KiB on average), full-size launch: whole 128-byte lines through a per-lane LDS window:
+                // 1.06x instead of 1.46x the algorithmic HBM reads for 1-2 % of time (2.82 vs 2.77 ms on rndm * 4096, warm).
+                // Below 1 KiB the window's per-string start-up shows (5 % at 600 B, 10 % at 200 B on average), and the
+                // per-lane 16-byte loads stay (profiles/r02_long_strings_line_window.txt)
                 hipLaunchKernelGGL((map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words,
                                    meta_dev, count, out, tile);
             else if (avg_words >= 32)
-                launch_direct(true);   // a short launch: smaller workgroups spread it over the chip
+                launch_direct(true);   // medium strings, or a short launch (smaller workgroups spread it over the chip)
             else
                 launch_staged(map_kernel<512, 1024, 17664, 0>, 512, 1024, 17664);
             break;
