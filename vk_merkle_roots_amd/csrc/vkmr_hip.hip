@@ -290,6 +290,9 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
             const uint64_t fit = want > 0.0 ? (uint64_t)want : 0;
             if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
         }
+        // a launch too short to give every CU its two workgroups: smaller tiles, so that it still spreads over the chip
+        const uint32_t spread = (uint32_t)((count / 512u) & ~63u);
+        if (spread < tile) tile = spread < max_tile / 4 ? max_tile / 4 : spread;
         hipLaunchKernelGGL(kern, dim3((uint32_t)(((uint64_t)count + tile - 1) / tile)), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
     };
     // tiles of up to 2048 strings, smaller when the batch is short so that it still
