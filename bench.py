@@ -287,7 +287,7 @@ def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=10):
     ops = blocks * SLOTS_BLOCK + n * SLOTS_DIGEST
     for buf in (d_data, d_meta, d_out):
         buf.free()
-    traffic = None   # HBM bytes per launch from the PMC passes over the same workload (tools/run_n.sh -> profiles/pmc_latest.json)
+    traffic = None   # HBM bytes per launch from the PMC passes over the same workload (tools/gpu_measurement_set.sh -> profiles/pmc_latest.json)
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         if rec.get("long_strings_workload") == f"rndm {seed} 2^{count_log2} {maxlen}, one batch" and not os.environ.get("VKMR_MAP_VARIANT"):
