@@ -8,8 +8,12 @@
 #pragma once
 #include <stdint.h>
 
-#define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel
-#define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass
+#ifndef VKMR_PASS_WAVES
+#define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel (2: 6 % slower, 8: the same -- profiles/r02_reduce_pass_shape.txt)
+#endif
+#ifndef VKMR_PASS_MAXM
+#define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass (2^5: 1 % slower)
+#endif
 
 namespace vkmr_plan {
 
