@@ -91,3 +91,15 @@ def test_product_does_not_reference_the_test_doubles():
             if re.search(r"fake_vkmr|virt_devices|tests/_build|VKMR_FAKE_|VKMR_TEST_VIRTUAL", t):
                 bad.append(f)
     assert not bad, bad
+
+
+def test_docs_name_only_entry_points_that_exist():
+    """INTEGRATION.md, DESIGN.md and README.md may only name `vkmr_hip_*` entry points the header declares (or host-library
+    helpers, `vkmr_host_*`): stale names in the binding guide would send a maintainer looking for functions that are gone."""
+    declared = set(declared_symbols())
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for name in set(re.findall(r"\b(vkmr_hip_[a-z0-9_]+)\b", text)):
+            if name in ("vkmr_hip_h", "vkmr_hip_comm_", "vkmr_hip_combine"):   # file name fragment / prefix mention / round-1 name discussed in DESIGN
+                continue
+            assert name in declared or name + "_async" in declared or name.rstrip("_") in {d[: len(name.rstrip("_"))] for d in declared}, (doc, name)
