@@ -75,3 +75,33 @@ def test_fork_join_pool_under_tsan(tmp_path):
                            os.path.join(ROOT, "tests", "c", "fork_join_test.cpp"), os.path.join(host, "stream_pack.cpp"), "-o", exe])
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and r.stdout.startswith(b"ok "), (r.stdout, r.stderr[-1500:])
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.lists(st.one_of(st.sampled_from([b"\n", b"\n\n", b"\r\n", b"x" * 63 + b"\n", b"y" * 64 + b"\n", b"z" * 65, b"q" * 200, b"\xff\x00"]),
+                          st.binary(min_size=0, max_size=90)), max_size=60),
+       st.integers(0, 5000), st.integers(0, 400), st.booleans(), st.integers(0, 7))
+def test_avx2_line_splitter_equals_the_portable_one(native, parts, cap_words, cap_meta, final, first_word):
+    """PackLines / CountLines find newlines 64 bytes at a time (AVX2) where the CPU can; line for line they must do what the
+    memchr-per-line forms do: same strings, same packed words, same bytes consumed when a buffer fills up mid-stream, same
+    treatment of an unfinished last line (final or not)."""
+    import ctypes as C
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    stream = b"".join(parts)
+    buf = np.frombuffer(stream, dtype=np.uint8) if stream else np.zeros(0, np.uint8)
+    ptr = buf.ctypes.data if len(stream) else None
+    a, b = np.zeros(5, np.uint64), np.zeros(5, np.uint64)
+    h.vkmr_host_count_lines(ptr, len(stream), 0, a.ctypes.data)
+    h.vkmr_host_count_lines(ptr, len(stream), 1, b.ctypes.data)
+    assert a.tolist() == b.tolist()
+    outs = []
+    for which in (0, 1):
+        data = np.full(first_word + cap_words + 8, 0xABABABAB, dtype=np.uint32)
+        meta = np.zeros((cap_meta + 1, 2), dtype=np.uint32)
+        out = np.zeros(5, np.uint64)
+        h.vkmr_host_pack_prefix(ptr, len(stream), int(final), data.ctypes.data, first_word, first_word + cap_words, meta.ctypes.data, cap_meta, which,
+                                out.ctypes.data)
+        outs.append((out.tolist(), data.tolist(), meta.tolist()))
+    assert outs[0] == outs[1]
+    assert outs[0][1][first_word + cap_words:] == [0xABABABAB] * 8      # nothing written past the capacity

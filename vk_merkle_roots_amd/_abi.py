@@ -80,6 +80,10 @@ HOST_SIGNATURES = {
     "vkmr_host_rndm_rand": (None, [C.c_uint32, C.c_void_p, C.c_uint64]),
     "vkmr_host_pack_lines": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vkmr_host_pack_lines_portable": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vkmr_host_count_lines": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
+    "vkmr_host_pack_prefix": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -34,4 +34,10 @@ PackResult PackLines(const uint8_t* buf, size_t len, bool final, uint32_t* data,
 struct LineCount { uint64_t strings, words, bytes, empties; bool too_long; };
 LineCount CountLines(const uint8_t* buf, size_t len);
 
+// The portable forms (one memchr per line).  PackLines / CountLines use AVX2 forms where the CPU has them (the newline
+// positions of 64 input bytes at a time); these stay as the reference the tests compare them with.
+PackResult PackLinesPortable(const uint8_t* buf, size_t len, bool final, uint32_t* data, uint64_t first_word,
+                             uint64_t data_capacity_words, vkmr_metadata* meta, uint64_t meta_capacity);
+LineCount CountLinesPortable(const uint8_t* buf, size_t len);
+
 }  // namespace vkmr
