@@ -515,14 +515,38 @@ def main():
                 torch.cuda.synchronize()
         dev.sync()
 
+    # A multi-rank run that wedges (a rank lost, a collective that never completes) should say where, not sit until the
+    # launcher's timeout: a watchdog thread ends the process with a message once a phase has taken implausibly long.
+    phase = {"name": "warmup", "since": time.time()}
+    if dist is not None:
+        import threading
+
+        def watchdog():
+            while True:
+                time.sleep(5)
+                if phase["name"] == "done":
+                    return
+                if time.time() - phase["since"] > 240:
+                    sys.stderr.write(f"[bench] rank {rank}: no progress for 240 s in phase '{phase['name']}' "
+                                     f"(collective {collective}); last error of the C ABI: {vk._abi.what_error()!r}\n")
+                    sys.stderr.flush()
+                    os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    def enter(name):
+        phase["name"], phase["since"] = name, time.time()
+
     for _ in range(a.warmup):
         step(False)
+    enter("barrier before the timed steps")
     barrier()
+    enter("timed steps")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
     barrier()
     dt = time.perf_counter() - t0
+    enter("after the timed steps")
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
@@ -632,11 +656,13 @@ def main():
         if world > 1 and comm is not None:
             out["hip_all_one_process_check"] = hip_all_check()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    enter("teardown")
     if comm is not None:
         dev.lib.vkmr_hip_comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    enter("done")
 
 
 if __name__ == "__main__":
