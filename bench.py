@@ -641,6 +641,31 @@ def main():
             out["pipeline_pcie_inclusive"] = {"leaf_hashes_per_s": pl["leaf_hashes_per_s"], "ms": pl["ms"], "h2d_GBps": pl["h2d_GBps"],
                                               "root_matches": digest_hex(pl["root"]) == root_hex,
                                               "what": "pinned host batches -> async H2D overlapped with map -> reduce -> root"}
+        if world == 1 and not a.no_pipeline and not a.levels_variant and nbatches == 1 and nslices == 1 and a.leaves_log2 > 23:
+            # the same step in the reference's shapes -- map launches of 2^23 strings (its batch, Batches.h:131-134), slices of
+            # 2^23 digests (its slice, SHA-256vk.cpp:23) reduced by one batched call, roots combined on the device -- for comparison
+            d_data, words, d_meta = d_batches[0]
+            sub, ns = 1 << 23, n >> 23
+            d_r8 = dev.alloc(32 * ns)
+            d_s8 = dev.alloc(dev.lib.vkmr_hip_reduce_slices_scratch_bytes(sub, ns))
+
+            def ref_step():
+                for b in range(ns):
+                    dev.map_async(d_data, words, d_meta, sub, d_digests, out_offset_digests=b * sub, meta_offset=b * sub)
+                dev.reduce_slices_async(d_digests, ns, sub, sub, 23, d_s8, d_r8)
+                dev.combine_async(d_r8, ns, d_top_scratch, d_final)
+                vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, d_final.ptr, 32), "d2h")
+                dev.sync()
+            ref_step()
+            t0r = time.perf_counter()
+            for _ in range(5):
+                ref_step()
+            dtr = (time.perf_counter() - t0r) / 5
+            out["reference_shapes"] = {"map_launches_per_step": ns, "slices": ns, "ms_per_step": dtr * 1e3, "leaf_hashes_per_s": n / dtr,
+                                       "root_matches": digest_hex(final) == root_hex,
+                                       "what": "batches of 2^23 strings, slices of 2^23 digests (the reference's shapes), same resident input"}
+            d_r8.free()
+            d_s8.free()
         if world == 1 and not a.no_pipeline and not a.levels_variant and nbatches == 1 and nslices == 1:
             ts = two_stream_rate(dev, vk, d_batches[0], bstr, n, slice_height)
             out["two_stream_overlap"] = {"leaf_hashes_per_s": ts["leaf_hashes_per_s"], "ms_per_step": ts["ms_per_step"], "what": ts["what"],
