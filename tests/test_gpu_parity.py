@@ -125,7 +125,8 @@ def test_map_into_sub_slice_offsets(gpu, oracle):
 
 # ---- reduce ----------------------------------------------------------------------
 
-COUNTS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 130, 255, 256, 257, 1000, 1023,
+COUNTS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 130, 191, 193, 255, 256, 257, 383, 385, 1000, 1023,
+          1151, 1153, 1919, 1921, 1985,
           1024, 1025, 2047, 2048, 2049, 2050, 4095, 4097, 5000, 8191, 8193, 65535, 65537, 100000, 262143, 524288,
           524289, 600001]
 
@@ -144,7 +145,7 @@ def test_reduce_to_capacity_height(gpu, oracle, variant):
     """A short last slice is reduced to the full slice height with self-pairing
     (reference Reductions.cpp:471, README.md:94)."""
     rng = np.random.default_rng(2)
-    for n, h in [(1, 1), (1, 5), (1, 23), (2, 4), (3, 10), (5, 3), (100, 12), (129, 23), (2049, 13), (2049, 20),
+    for n, h in [(1, 1), (1, 5), (1, 23), (2, 4), (3, 10), (5, 3), (100, 12), (129, 23), (130, 9), (257, 9), (1500, 14), (2047, 11), (2048, 11), (2048, 23), (2049, 13), (2049, 20),
                  (5000, 23), (70000, 17), (70000, 23), (300000, 20)]:
         leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
         got = gpu.reduce_digests(leaves, height=h, levels_variant=(variant == "levels"))

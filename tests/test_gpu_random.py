@@ -79,11 +79,13 @@ def test_random_map_length_mixes(gpu, oracle):
         assert (got == want).all(), (case, kind, n)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "9", "10"])
 def test_every_fetch_mode_of_the_map_kernel_is_bit_exact(variant):
-    """The map kernel's alternative fetch modes (VKMR_MAP_VARIANT, read once per process: LDS-staged 64 / 32 KiB tiles,
-    per-wavefront gather, per-lane 16-byte loads, line window) against the oracle on short, long, ragged, unordered and
-    out-of-range inputs -- whichever mode a launch picks, the digests are the same."""
+    """The map kernel's fetch modes against the oracle on short, long, ragged, unordered and out-of-range inputs --
+    whichever mode a launch picks, the digests are the same.  "0" is the product library choosing from the batch alone;
+    the others force one mode through the EXPERIMENTS build (build/ab/libexp.so, VKMR_MAP_VARIANT read once per process:
+    LDS-staged 64 / 32 KiB tiles, per-wavefront gather, per-lane 16-byte loads, line window, and the north star's
+    K-in-LDS / schedule-ring-in-LDS forms of the compression)."""
     import os
     import subprocess
     import sys
@@ -114,6 +116,11 @@ vk.check(gpu.lib.vkmr_hip_map_async(gpu.index, gpu.stream, d_all.at(20), b.words
 assert (gpu.download(d_out, 32 * b.count).reshape(-1, 8) == o.leaves_packed(b.data, b.meta, threads=8)).all()
 print("ok")
 ''' % (ROOT, ROOT)
-    env = dict(os.environ, VKMR_MAP_VARIANT=variant)
+    env = dict(os.environ)
+    env.pop("VKMR_HIP_LIB", None)
+    if variant != "0":
+        from vk_merkle_roots_amd.build import EXP_LIB
+        assert os.path.exists(EXP_LIB), "experiments library not built (vk_merkle_roots_amd.build.build_experiments)"
+        env.update(VKMR_MAP_VARIANT=variant, VKMR_HIP_LIB=EXP_LIB)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr[-2000:].decode()

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""The shader clock the chip HOLDS inside the shipped kernels, measured in-kernel.
+
+Loads the diagnostic twin of the product library (vk_merkle_roots_amd/libvkmr_hip_stamps.so: the same source built
+with -DVKMR_STAMPS, nothing else changed).  In it lane 0 of every workgroup's first wavefront stamps s_memtime (shader
+cycles) and s_memrealtime (constant 100 MHz) at its first and last instruction into a buffer no kernel reads; the clock
+of a workgroup is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md "DVFS give-back" item 6: after >= 2 s of
+back-to-back launches on random data; s_memtime counters are per XCD, so only per-workgroup differences are used).
+Board power and the driver's sclk are sampled from sysfs hwmon beside it.  Prints one JSON object (last line).
+
+    python3 tools/kernel_clock.py [--leaves-log2 24] [--maxlen 127] [--seconds 2.0]        # GPU box only
+"""
+import argparse
+import ctypes as C
+import glob
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vk_merkle_roots_amd.build import STAMPS_LIB  # noqa: E402
+
+os.environ["VKMR_HIP_LIB"] = STAMPS_LIB
+import vk_merkle_roots_amd as vk  # noqa: E402
+
+SLOTS = 65536
+
+
+def _first(pattern):
+    g = sorted(glob.glob(pattern))
+    return g[0] if g else None
+
+
+class Hwmon:
+    """Board power (W) and the driver's shader clock (MHz) from sysfs; every field may be missing."""
+
+    def __init__(self):
+        base = "/sys/class/drm/card*/device/hwmon/hwmon*/"
+        self.power = _first(base + "power1_average") or _first(base + "power1_input")
+        self.cap = _first(base + "power1_cap")
+        self.sclk = _first(base + "freq1_input")
+
+    @staticmethod
+    def read(path, scale):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0]) / scale
+        except Exception:
+            return None
+
+
+def sustained(dev, launch, seconds, hw):
+    """`seconds` of back-to-back launches with hwmon sampled from a side thread; returns (ms per launch, power W, sclk MHz)."""
+    stop, pw, sk = threading.Event(), [], []
+
+    def sample():
+        while not stop.is_set():
+            p, s = Hwmon.read(hw.power, 1e6), Hwmon.read(hw.sclk, 1e6)
+            if p:
+                pw.append(p)
+            if s:
+                sk.append(s)
+            time.sleep(0.02)
+
+    t = threading.Thread(target=sample)
+    launch(); dev.sync()
+    t.start()
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(8):
+            launch()
+        dev.sync(); n += 8
+    dt = time.time() - t0
+    stop.set(); t.join()
+    med = lambda v: float(np.median(v)) if v else None  # noqa: E731
+    return dt / n * 1e3, med(pw), med(sk)
+
+
+def read_stamps(L, tag):
+    buf = np.empty(SLOTS * 8, dtype=np.uint64)
+    buf.fill(0)   # touched pages: a GPU copy into never-written calloc pages faults ("write access to a read-only page")
+    assert L.vkmr_hip_debug_stamps(C.c_void_p(buf.ctypes.data), SLOTS * 8) == 0
+    s = buf.reshape(SLOTS, 8)
+    s = s[(s[:, 6] == tag) & (s[:, 5] > s[:, 1])]
+    if len(s):
+        s = s[s[:, 7] == s[:, 7].max()]      # the widest launch of that kernel (bulk pass 0), not the later, smaller ones
+    return s.astype(np.float64)
+
+
+def clock_of(s):
+    ghz = (s[:, 4] - s[:, 0]) / (s[:, 5] - s[:, 1]) * 0.1
+    return {"GHz_median": round(float(np.median(ghz)), 4), "GHz_p5": round(float(np.percentile(ghz, 5)), 4),
+            "GHz_p95": round(float(np.percentile(ghz, 95)), 4), "workgroups_stamped": int(len(s)),
+            "cycles_per_workgroup_median": float(np.median(s[:, 4] - s[:, 0]))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--leaves-log2", type=int, default=24)
+    ap.add_argument("--maxlen", type=int, default=127)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--seconds", type=float, default=2.0)
+    a = ap.parse_args()
+    dev = vk.HipDevice(0)
+    L = C.CDLL(STAMPS_LIB)
+    hw = Hwmon()
+    b = vk.rndm_packed(a.seed, 1 << a.leaves_log2, a.maxlen)
+    d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * b.count)
+    d_scr, d_root = dev.reduce_scratch(b.count), dev.alloc(32)
+    height = vk.tree_height(b.count)
+    out = {"workload": f"rndm {a.seed} 2^{a.leaves_log2} {a.maxlen}", "library": os.path.relpath(STAMPS_LIB, ROOT),
+           "method": "per-workgroup d(s_memtime)/d(s_memrealtime) x 100 MHz after >= %.1f s of back-to-back launches" % a.seconds,
+           "power_cap_W": Hwmon.read(hw.cap, 1e6)}
+    e0, e1 = dev.new_event(), dev.new_event()
+
+    def one(name, tag, launch):
+        ms_sus, pw, sk = sustained(dev, launch, a.seconds, hw)
+        L.vkmr_hip_debug_stamps(None, 0)   # clear
+        dev.record(e0); launch(); dev.record(e1); dev.sync()
+        s = read_stamps(L, tag)
+        rec = clock_of(s)
+        rec.update(ms_per_launch_sustained=round(ms_sus, 4), ms_stamped_launch=round(dev.elapsed_ms(e0, e1), 4),
+                   board_power_W=pw, sclk_sysfs_MHz=sk, kernel=dev.lib.vkmr_hip_kernel_info().decode().split(" reduce=")[0] if tag == 0x4d4150 else "reduce_pass_kernel (first bulk pass)")
+        if tag == 0x4d4150 and len(s):   # phases of a map workgroup's first wavefront
+            life = s[:, 4] - s[:, 0]
+            rec["phase_share"] = {"sort": round(float(np.median((s[:, 2] - s[:, 0]) / life)), 4),
+                                  "stage": round(float(np.median((s[:, 3] - s[:, 2]) / life)), 4),
+                                  "hash": round(float(np.median((s[:, 4] - s[:, 3]) / life)), 4)}
+        out[name] = rec
+
+    one("map_kernel", 0x4d4150, lambda: dev.map_async(d_data, b.words, d_meta, b.count, d_out))
+    one("reduce_pass_kernel", 0x524544, lambda: dev.reduce_async(d_out, b.count, height, d_scr, d_root))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -5,51 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../vk_merkle_roots_amd/csrc/sha256d_device.hpp"
+#include "../vk_merkle_roots_amd/csrc/experiments/sha256d_lds.hpp"
 
 using namespace vkmr_dev;
-
-template <int T, bool W_LDS>
-__device__ __forceinline__ void lds_round(uint32_t (&s)[8], uint32_t (&w)[16], const uint32_t* sK, uint32_t* sW)
-{
-    constexpr int i = T & 15;
-    uint32_t wt;
-    if (W_LDS) {
-        // schedule ring lives in LDS: this lane's 16 words at sW[j * blockDim.x] (conflict-free)
-        if (T >= 16) {
-            const uint32_t w0 = sW[i * 256], w1 = sW[((i + 1) & 15) * 256], w9 = sW[((i + 9) & 15) * 256], w14 = sW[((i + 14) & 15) * 256];
-            wt = w0 + ssig0(w1) + w9 + ssig1(w14);
-            sW[i * 256] = wt;
-        } else {
-            wt = sW[i * 256];
-        }
-    } else {
-        if (T >= 16) w[i] = w[i] + ssig0(w[(i + 1) & 15]) + w[(i + 9) & 15] + ssig1(w[(i + 14) & 15]);
-        wt = w[i];
-    }
-    round_fn<T>(s, sK[T] + wt);
-}
-
-template <bool W_LDS, int... T>
-__device__ __forceinline__ void lds_rounds(uint32_t (&s)[8], uint32_t (&w)[16], const uint32_t* sK, uint32_t* sW, std::integer_sequence<int, T...>)
-{
-    (lds_round<T, W_LDS>(s, w, sK, sW), ...);
-}
-
-template <bool W_LDS>
-__device__ __forceinline__ void lds_compress(uint32_t (&H)[8], uint32_t (&w)[16], const uint32_t* sK, uint32_t* sW)
-{
-    uint32_t s[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = H[i];
-    if (W_LDS) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sW[i * 256] = w[i];
-    }
-    lds_rounds<W_LDS>(s, w, sK, sW, std::make_integer_sequence<int, 64>{});
-#pragma unroll
-    for (int i = 0; i < 8; ++i) H[i] += s[i];
-}
 
 template <int VARIANT>
 __global__ __launch_bounds__(256) void node_kernel(const Node* in, Node* out, int reps)
@@ -71,19 +29,19 @@ __global__ __launch_bounds__(256) void node_kernel(const Node* in, Node* out, in
             uint32_t w[16], H[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { w[i] = l[i]; w[8 + i] = r[i]; H[i] = IV256[i]; }
-            lds_compress<VARIANT == 2>(H, w, sK, sW);
+            lds_compress<VARIANT == 2, 256>(H, w, sK, sW);
             w[0] = 0x80000000u;
 #pragma unroll
             for (int i = 1; i < 15; ++i) w[i] = 0u;
             w[15] = 512u;
-            lds_compress<VARIANT == 2>(H, w, sK, sW);
+            lds_compress<VARIANT == 2, 256>(H, w, sK, sW);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { w[i] = H[i]; o[i] = IV256[i]; }
             w[8] = 0x80000000u;
 #pragma unroll
             for (int i = 9; i < 15; ++i) w[i] = 0u;
             w[15] = 256u;
-            lds_compress<VARIANT == 2>(o, w, sK, sW);
+            lds_compress<VARIANT == 2, 256>(o, w, sK, sW);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { l[i] = o[i]; r[i] ^= o[i]; }

@@ -5,6 +5,9 @@ gfx950 without a GPU.  Outputs land next to the package so that they travel to
 the GPU box with the source snapshot:
 
     vk_merkle_roots_amd/libvkmr_hip.so   HIP kernels + the C ABI (include/vkmr_hip.h)
+    vk_merkle_roots_amd/libvkmr_hip_stamps.so   DIAGNOSTIC build of the same source with -DVKMR_STAMPS: in-kernel
+                                         s_memtime / s_memrealtime stamps (tools/kernel_clock.py, bench.py's
+                                         measured shader clock).  Never loaded by the product.
     vk_merkle_roots_amd/libvkmr_host.so  host-side helpers (stream packing, rndm generator)
     vk_merkle_roots_amd/bin/{vkmr,rndm,strm}  the C++ front end and its two feeder tools
 """
@@ -20,7 +23,10 @@ HOST = os.path.join(CSRC, "host")
 BIN = os.path.join(PKG, "bin")
 HIP_LIB = os.path.join(PKG, "libvkmr_hip.so")
 HOST_LIB = os.path.join(PKG, "libvkmr_host.so")
+STAMPS_LIB = os.path.join(PKG, "libvkmr_hip_stamps.so")
+EXP_LIB = os.path.join(ROOT, "build", "ab", "libexp.so")
 ARCH = "gfx950"
+PRIO_GAP = 0    # isa_prio_pass: complex-instruction runs separated by at most this many simple instructions are merged
 
 
 def _hipcc():
@@ -54,14 +60,63 @@ def _tree(d, exts):
     return sorted(out)
 
 
+def _llvm(tool):
+    for d in (os.environ.get("ROCM_LLVM_BIN"), "/opt/rocm/lib/llvm/bin", "/opt/rocm/llvm/bin"):
+        if d and os.path.exists(os.path.join(d, tool)):
+            return os.path.join(d, tool)
+    raise RuntimeError(f"{tool} not found under /opt/rocm/lib/llvm/bin")
+
+
+def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP):
+    """hipcc in five explicit steps so that the issue-priority pass (isa_prio_pass.py) can run on the device assembly:
+    device code -> .s, pass, assemble + link the code object, bundle it, compile the host side around that bundle.
+    prio_gap None = plain one-step hipcc build (no pass), for A/B timing."""
+    src = os.path.join(CSRC, "vkmr_hip.hip")
+    deps = [src, os.path.join(PKG, "isa_prio_pass.py"), os.path.abspath(__file__)] + _tree(CSRC, (".hpp", ".h")) + [os.path.join(ROOT, "include", "vkmr_hip.h")]
+    if not force and _newer(target, deps):
+        return target
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    common = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden"] + defines
+    if prio_gap is None:
+        _run([_hipcc()] + common + ["-shared", "-Wl,-rpath,/opt/rocm/lib", "-o", target, src])
+        return target
+    work = os.path.join(ROOT, "build", "obj", os.path.basename(target))
+    os.makedirs(work, exist_ok=True)
+    dev_s, prio_s = os.path.join(work, "device.s"), os.path.join(work, "device_prio.s")
+    dev_o, dev_co, fatbin, host_o = (os.path.join(work, n) for n in ("device.o", "device.co", "device.hipfb", "host.o"))
+    _run([_hipcc()] + common + ["--cuda-device-only", "-S", "-o", dev_s, src])
+    from . import isa_prio_pass
+    with open(dev_s) as f:
+        lines = f.readlines()
+    out, stats = isa_prio_pass.transform(lines, prio_gap)
+    with open(prio_s, "w") as f:
+        f.writelines(out)
+    _run([_llvm("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", prio_s, "-o", dev_o])
+    _run([_llvm("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_co, dev_o])
+    _run([_llvm("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+          f"-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--{ARCH}", "-input=/dev/null", f"-input={dev_co}", f"-output={fatbin}"])
+    _run([_hipcc()] + common + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-o", host_o])
+    _run([_hipcc(), "-shared", "-Wl,-rpath,/opt/rocm/lib", "-o", target, host_o])
+    with open(os.path.join(work, "prio_pass_stats.txt"), "w") as f:
+        f.write(repr(stats) + "\n")
+    return target
+
+
 def build_hip(force=False):
-    srcs = [os.path.join(CSRC, "vkmr_hip.hip")]
-    deps = srcs + _tree(CSRC, (".hpp", ".h")) + [os.path.join(ROOT, "include", "vkmr_hip.h")]
-    if not force and _newer(HIP_LIB, deps):
-        return HIP_LIB
-    _run([_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden",
-          "-Wl,-rpath,/opt/rocm/lib", "-o", HIP_LIB] + srcs)
-    return HIP_LIB
+    """The product library: no experiment knobs, no stamps."""
+    return _build_hip_variant(HIP_LIB, [], force)
+
+
+def build_stamps(force=False):
+    """Diagnostic twin of the product library (same source, -DVKMR_STAMPS): measures the shader clock the chip
+    holds inside map_kernel / reduce_pass_kernel.  Loaded only through VKMR_HIP_LIB by tools and bench.py's clock leg."""
+    return _build_hip_variant(STAMPS_LIB, ["-DVKMR_STAMPS"], force)
+
+
+def build_experiments(force=False):
+    """Tools build (-DVKMR_EXPERIMENTS): the A/B knobs VKMR_MAP_VARIANT/_FIT/_TILE/_DYNLDS and the non-shipped
+    map_kernel instantiations (csrc/map_experiments.hpp).  Lands under build/ab/, not in the package."""
+    return _build_hip_variant(EXP_LIB, ["-DVKMR_EXPERIMENTS"], force)
 
 
 def build_host(force=False):
@@ -106,7 +161,7 @@ def build_host(force=False):
 
 
 def build_all(force=False):
-    out = [build_hip(force)]
+    out = [build_hip(force), build_stamps(force), build_experiments(force)]
     out += build_host(force)
     return out
 
@@ -114,3 +169,4 @@ def build_all(force=False):
 if __name__ == "__main__":
     for p in build_all(force="--force" in sys.argv):
         print(p)
+

@@ -6,6 +6,10 @@
 
 #include "../../include/vkmr_hip.h"
 #include "sha256d_device.hpp"
+#include "stamps.hpp"
+#ifdef VKMR_EXPERIMENTS
+#include "experiments/sha256d_lds.hpp"
+#endif
 
 using vkmr_dev::Node;
 
@@ -44,15 +48,6 @@ using vkmr_dev::Node;
 #define VKMR_MAP_WIN_STRIDE 68      // words per lane row of the line window: two 32-word lines + 4, so that the
                                     // ds_write_b128 of 16 consecutive lanes lands on all 64 banks
 
-#ifdef VKMR_MAP_STAMPS
-// Diagnostic build only (tools/map_stamps.py): per-phase shader-clock totals of the map
-// kernel, accumulated by lane 0 of every workgroup.  Never compiled into the product.
-__device__ unsigned long long g_map_stamps[32768 * 8];   // 8 words per workgroup, no atomics
-#define VKMR_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define VKMR_STAMP(var)
-#endif
-
 // One 128-byte line of the packed buffer, `li` = its first word's index (a multiple of 32 words counted from a
 // 128-byte-aligned address; negative for the line that contains data[0] when the buffer itself is not aligned).
 // Words outside [0, data_words) read as zero.  `want` = this lane needs the line at all.
@@ -85,7 +80,10 @@ __device__ __forceinline__ uint32_t block_count(uint32_t size) { return (uint32_
 // exception, simply per lane.
 // FULLFAST adds a wave-uniform fast path for blocks in which every string of the group
 // still has 64 bytes (long strings); short-string batches are faster without the test.
-template <int THREADS, int MAX_TILE, int STAGE_WORDS, int MODE, bool FULLFAST = false>
+// SCHED (experiments build only): 0 = the shipped compression (K as literals, schedule ring in VGPRs), 1 = K[64] in
+// LDS, 2 = K and the 16-word schedule ring in LDS -- the north star's wording, timed inside this kernel
+// (profiles/r03_map_lds_schedule_ab.txt).
+template <int THREADS, int MAX_TILE, int STAGE_WORDS, int MODE, bool FULLFAST = false, int SCHED = 0>
 __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict__ data, uint64_t data_words,
                                                       const vkmr_metadata* __restrict__ meta, uint32_t count,
                                                       Node* __restrict__ out, uint32_t tile)
@@ -103,6 +101,14 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
     __shared__ unsigned long long s_lo, s_hi;
     __shared__ uint32_t s_next;
     uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_stage4);
+#ifdef VKMR_EXPERIMENTS
+    __shared__ uint32_t s_K[SCHED ? 64 : 1];
+    __shared__ uint32_t s_W[SCHED == 2 ? 16 * THREADS : 1];
+    if (SCHED != 0 && threadIdx.x < 64) s_K[threadIdx.x] = vkmr_dev::K256[threadIdx.x];   // published by the barriers below
+    uint32_t* const my_W = s_W + (SCHED == 2 ? threadIdx.x : 0);
+#else
+    static_assert(SCHED == 0, "the LDS-schedule variants exist in the experiments build only");
+#endif
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t tile_base = (uint64_t)blockIdx.x * tile;
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
     const uint32_t n_tile = (uint32_t)((count - tile_base < tile) ? count - tile_base : tile);
 
     VKMR_STAMP(t_begin);
+    VKMR_STAMP_RT(rt_begin);
     // The prologue (sort + staging) is a few hundred instructions; a freshly launched
     // workgroup is the youngest on its SIMDs and would otherwise be starved by the older
     // workgroups' hashing, holding its LDS and wave slots idle.  Raise its issue priority
@@ -341,21 +348,31 @@ __global__ __launch_bounds__(THREADS) void map_kernel(const uint32_t* __restrict
                 w[14] = size >> 29;
                 w[15] = size << 3;
             }
+#ifdef VKMR_EXPERIMENTS
+            if (SCHED != 0) {
+                if (b < nb) vkmr_dev::lds_compress<SCHED == 2, THREADS>(H, w, s_K, my_W);
+            } else
+#endif
             if (b < nb) vkmr_dev::compress(H, w);
         }
         if (has) {
             uint32_t o[8];
+#ifdef VKMR_EXPERIMENTS
+            if (SCHED != 0) vkmr_dev::lds_hash_digest<SCHED == 2, THREADS>(H, o, s_K, my_W);
+            else
+#endif
             vkmr_dev::hash_digest(H, o);
             vkmr_dev::store_node(out + tile_base + id, o);
         }
     }
-#ifdef VKMR_MAP_STAMPS
+#ifdef VKMR_STAMPS
     {
         unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        unsigned long long rt = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0 && blockIdx.x < 32768u) {   // wavefront 0 of each workgroup: its own phase boundaries
-            unsigned long long* o = g_map_stamps + (size_t)blockIdx.x * 8;
-            o[0] = t_begin; o[1] = t_sorted; o[2] = t_staged; o[3] = t_end; o[4] = rt;
+        unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < VKMR_STAMP_SLOTS) {   // wavefront 0 of each workgroup: its own phase boundaries
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            o[0] = t_begin; o[1] = rt_begin; o[2] = t_sorted; o[3] = t_staged; o[4] = t_end; o[5] = rt_end;
+            o[6] = 0x4d4150ull /* "MAP" */; o[7] = gridDim.x;
         }
     }
 #endif

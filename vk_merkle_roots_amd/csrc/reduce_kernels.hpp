@@ -7,6 +7,7 @@
 
 #include "reduce_plan.hpp"   // VKMR_PASS_WAVES, VKMR_PASS_MAXM and the host-side schedule
 #include "sha256d_device.hpp"
+#include "stamps.hpp"
 
 using vkmr_dev::Node;
 
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
     const uint64_t base0 = gwave * (128ull << m);
     if (base0 >= n_in) return;   // wave-uniform; no workgroup barrier is used below
     Node* pend = reinterpret_cast<Node*>(pend_store) + wave * (VKMR_PASS_MAXM * 64);
+    VKMR_STAMP(t_begin);
+    VKMR_STAMP_RT(rt_begin);
 
     uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t chunks = 1u << m;
@@ -110,15 +113,25 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
     }
     const uint64_t jo = (base0 >> (m + 1)) + lane;
     if (jo < level_count(n_in, m + 1)) vkmr_dev::store_node(out + jo, X);
+#ifdef VKMR_STAMPS
+    {
+        unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < VKMR_STAMP_SLOTS) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            o[0] = t_begin; o[1] = rt_begin; o[2] = t_begin; o[3] = t_begin; o[4] = t_end; o[5] = rt_end;
+            o[6] = 0x524544ull /* "RED" */; o[7] = gridDim.x;
+        }
+    }
+#endif
 }
 
-// Top of the tree: up to VKMR_TAIL_MAX nodes, exactly `levels` levels, one
-// workgroup.  Level 1 comes from a coalesced pair load; the next six levels stay
-// inside each 64-lane wavefront with __shfl_down, exactly the shape of the
-// reference's subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377); up to
-// sixteen wave results then meet in LDS and one wave finishes with __shfl_down.
-// Any levels left once a single node remains hash that node with itself
-// ("keep iterating", README.md:94).
+// Top of the tree: up to VKMR_TAIL_MAX = 2048 nodes, exactly `levels` levels, one workgroup of
+// ceil(n/128) wavefronts (reduce_plan.hpp: tail_threads).  Level 1 comes from a coalesced pair load; the next
+// six levels stay inside each 64-lane wavefront with __shfl_down, exactly the shape of the reference's
+// subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377); up to sixteen wave results then meet in LDS and
+// wavefront 0 finishes with __shfl_down.  Any levels left once a single node remains hash that node with
+// itself ("keep iterating", README.md:94).
 __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0, uint32_t lane, uint64_t n_in,
                                                  uint32_t& done, uint32_t levels, uint32_t steps)
 {
@@ -142,7 +155,7 @@ __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0
     }
 }
 
-__global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+__global__ __launch_bounds__(VKMR_TAIL_MAX / 2) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
                                                            Node* __restrict__ root0)
 {
     const uint32_t n_in = (uint32_t)slice_count(geom);
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restric
     }
     done = 1;
     shuffle_collapse(X, tid, lane, n_in, done, levels, 6);
-    if (done < levels) {   // uniform across the workgroup
+    if (blockDim.x > 64u && done < levels) {   // uniform across the workgroup: several wavefronts meet in LDS
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) wave_out[wave].w[i] = X[i];
@@ -176,13 +189,15 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(const Node* __restric
                 for (int i = 0; i < 8; ++i) X[i] = wave_out[lane].w[i];
             }
             shuffle_collapse(X, lane, lane, n_in, done, levels, 4);
-            while (done < levels) {   // a single node left: pair it with itself
-                uint32_t o[8];
-                vkmr_dev::hash_pair(X, X, o);
+        }
+    }
+    if (wave == 0) {
+        while (done < levels) {   // a single node left: pair it with itself (wave-uniform loop)
+            uint32_t o[8];
+            vkmr_dev::hash_pair(X, X, o);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) X[i] = o[i];
-                ++done;
-            }
+            for (int i = 0; i < 8; ++i) X[i] = o[i];
+            ++done;
         }
     }
     if (tid == 0) vkmr_dev::store_node(root, X);

@@ -15,6 +15,10 @@
 #define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass (2^5: 1 % slower)
 #endif
 
+#ifndef VKMR_TAIL_MAX
+#define VKMR_TAIL_MAX 2048  // reduce_tail_kernel takes up to this many nodes: 1024 lanes = 16 wavefronts of one workgroup
+#endif
+
 namespace vkmr_plan {
 
 inline uint64_t ceil_shift(uint64_t n, unsigned k) { return k >= 64 ? (n ? 1 : 0) : (n >> k) + ((n & ((1ull << k) - 1ull)) ? 1ull : 0ull); }
@@ -31,18 +35,29 @@ inline uint32_t pick_m(uint64_t n, uint32_t nslices)
 
 // One step of the reduction schedule for n nodes per slice with `left` levels to go:
 //   bulk     n/128 >= 2048 wavefronts: reduce_pass_kernel, m+1 levels, every lane busy
-//   collapse 128 < n: reduce_collapse_kernel, 7 levels, one wavefront per workgroup
-//   tail     n <= 128: reduce_tail_kernel, one wavefront, all remaining levels
+//   tail     n <= TAIL_MAX (2048) and too few wavefronts for a bulk pass: reduce_tail_kernel, one workgroup of
+//            ceil(n/128) wavefronts, all remaining levels
+//   collapse otherwise: reduce_collapse_kernel, 7 levels, one wavefront per workgroup
 struct Step { int kind; uint32_t levels; uint64_t n_out; };
 enum { STEP_BULK = 0, STEP_COLLAPSE = 1, STEP_TAIL = 2 };
+
+// Lanes of the tail workgroup for n nodes: one per pair, whole wavefronts.
+inline uint32_t tail_threads(uint64_t n)
+{
+    const uint64_t pairs = (n + 1) >> 1;
+    const uint64_t t = (pairs + 63) & ~63ull;
+    return t < 64 ? 64u : (uint32_t)t;
+}
 
 inline Step next_step(uint64_t n, uint32_t left, uint32_t nslices)
 {
     Step st;
     if (n <= 128) {
         st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
-    } else if (ceil_shift(n, 7) * nslices >= 2048) {
+    } else if (ceil_shift(n, 7) * nslices >= 2048) {   // many slices keep every lane busy even on short runs
         st.kind = STEP_BULK; st.levels = pick_m(n, nslices) + 1u; st.n_out = ceil_shift(n, st.levels);
+    } else if (n <= VKMR_TAIL_MAX) {
+        st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
     } else {
         st.kind = STEP_COLLAPSE; st.levels = 7; st.n_out = ceil_shift(n, 7);
     }
@@ -54,8 +69,10 @@ inline Step next_step(uint64_t n, uint32_t left, uint32_t nslices)
 inline uint64_t cells_written(uint64_t n, uint32_t nslices)
 {
     uint64_t total = 0;
-    for (int pass = 0; pass < 2 && n > 128; ++pass) {
-        n = next_step(n, 64, nslices).n_out;
+    for (int pass = 0; pass < 2; ++pass) {
+        const Step st = next_step(n, 64, nslices);
+        if (st.kind == STEP_TAIL) break;   // the tail writes the root, not scratch
+        n = st.n_out;
         total += n;
     }
     return total;

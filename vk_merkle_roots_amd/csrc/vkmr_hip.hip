@@ -61,17 +61,18 @@ extern "C" {
 
 const char* vkmr_hip_last_error(void) { return g_err; }
 
-#ifdef VKMR_MAP_STAMPS
+#ifdef VKMR_STAMPS
+// diagnostic build only: copies the stamp buffer out and clears it for the next launch
 __attribute__((visibility("default"))) int vkmr_hip_debug_stamps(unsigned long long* out, int words)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_map_stamps), sizeof(unsigned long long) * words) == hipSuccess ? 0 : -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * words) != hipSuccess) return -1;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * VKMR_STAMP_SLOTS * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 
-const char* vkmr_hip_kernel_info(void)
-{
-    return "map=map_kernel(tile-sorted by block count; LDS-staged tiles below 128 B on average, per-lane 16-byte loads up to 1 KiB, whole lines through a per-lane LDS window above) reduce=reduce_pass_kernel(m<=4)+reduce_collapse_kernel+reduce_tail_kernel";
-}
+const char* vkmr_hip_kernel_info(void);   // defined after the map entry point: it reports what the last launch chose
 
 vkmr_status vkmr_hip_device_count(int* count)
 {
@@ -263,6 +264,55 @@ vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end,
 
 // ---- map ------------------------------------------------------------------------
 
+// What the last vkmr_hip_map_async of this process chose (reported by vkmr_hip_kernel_info).
+enum { MAP_NONE = 0, MAP_STAGED, MAP_DIRECT512, MAP_DIRECT256, MAP_LINEWIN, MAP_EXPERIMENT };
+static int g_last_map_mode = MAP_NONE;
+static uint32_t g_last_map_tile = 0;
+
+// The shipped fetch modes (csrc/map_kernel.hpp).  The mode is chosen from the batch alone:
+//   average packed string < 128 B                    LDS-staged tiles (HBM traffic == algorithmic bytes)
+//   >= 1 KiB on average, full-size launch            whole 128-byte lines through a per-lane LDS window
+//   in between, or a launch too short for 512 lanes  per-lane 16-byte loads
+#define VKMR_MAP_STAGED_KERNEL map_kernel<512, 1024, 17664, 0, false>
+#define VKMR_MAP_LINEWIN_KERNEL map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>
+#define VKMR_MAP_DIRECT512_KERNEL map_kernel<512, 2048, 64, 2, true>
+#define VKMR_MAP_DIRECT256_KERNEL map_kernel<256, 2048, 64, 2, true>
+
+// Strings per LDS-staged tile: what is expected to fit the staging area, three standard deviations of a tile's
+// size below it (string lengths spread like rndm's, uniform in [1, max]: sigma / mean of T strings is about
+// 0.6 / sqrt(T)); a tile that overflows anyway falls back to per-lane loads inside the kernel.  The more strings a
+// tile sorts the better: fewer of its groups straddle a block-count boundary, and 1024 strings are exactly two
+// groups of 64 for each of the 8 wavefronts (profiles/r02_map_tile_fill.txt).  69 KiB of staging is what still
+// lets two workgroups share a CU's LDS.  `fit_pct` (experiments build only) replaces the 3-sigma rule.
+static uint32_t staged_tile(uint64_t data_words, uint32_t count, uint32_t max_tile, uint32_t stage_words, int fit_pct = 0)
+{
+    uint32_t tile = max_tile;
+    if (data_words > 0) {
+        const double r = (double)stage_words * (double)count / (double)data_words;   // strings that fill the area on average
+        const double want = fit_pct ? r * fit_pct / 100.0 : r * (1.0 - 1.8 / __builtin_sqrt(r > 4.0 ? r : 4.0));
+        const uint64_t fit = want > 0.0 ? (uint64_t)want : 0;
+        if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
+    }
+    // a launch too short to give every CU its two workgroups: smaller tiles, so that it still spreads over the chip
+    const uint32_t spread = (uint32_t)((count / 512u) & ~63u);
+    if (spread < tile) tile = spread < max_tile / 4 ? max_tile / 4 : spread;
+    return tile;
+}
+
+// Tiles of the per-lane modes: up to 2048 strings, smaller when the batch is short so that it still spreads over
+// the chip (>= ~1024 workgroups when it can).
+static uint32_t direct_tile(uint32_t count)
+{
+    const uint32_t tile = (count / 1024u) & ~63u;
+    return tile < 256u ? 256u : (tile > 2048u ? 2048u : tile);
+}
+
+static inline uint32_t tiles_of(uint32_t count, uint32_t tile) { return (uint32_t)(((uint64_t)count + tile - 1) / tile); }   // count + tile can pass 2^32
+
+#ifdef VKMR_EXPERIMENTS
+#include "map_experiments.hpp"   // tools build only: VKMR_MAP_VARIANT / _FIT / _TILE / _DYNLDS and the non-shipped instantiations
+#endif
+
 vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev, uint64_t data_words,
                                const vkmr_metadata* meta_dev, uint32_t count, vkmr_digest* out_dev)
 {
@@ -270,83 +320,60 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     if (!meta_dev || !out_dev || (!data_dev && data_words != 0))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_map_async: null pointer");
     VKMR_TRY(hipSetDevice(dev));
-    // VKMR_MAP_VARIANT picks an alternative fetch mode / geometry for A/B timing; 0 = shipped.
-    static const int variant = [] { const char* e = getenv("VKMR_MAP_VARIANT"); return e ? atoi(e) : 0; }();
     const uint64_t avg_words = (data_words + count - 1) / count;
     Node* out = reinterpret_cast<Node*>(out_dev);
-    // staged mode: strings per tile = what is expected to fit the LDS staging area, three standard deviations of a
-    // tile's size below it (string lengths spread like rndm's, uniform in [1, max]: sigma / mean of T strings is about
-    // 0.6 / sqrt(T)); a tile that overflows anyway falls back to per-lane loads.  The more strings a tile sorts the
-    // better: fewer of its groups straddle a block-count boundary, and 1024 strings are exactly two groups of 64 for
-    // each of the 8 wavefronts (896 strings leave two of them idle for half of the tile): 6.56 ms per 2^26 strings of
-    // rndm * 127 with 69 KiB / 1024 strings against 6.58 (68 KiB / 960), 6.70 (64 KiB / 896) and 6.78 (64 KiB / 832,
-    // round 1's shape) -- profiles/r02_map_tile_fill.txt.  69 KiB is what still lets two workgroups share a CU's LDS.
-    auto launch_staged = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
-        uint32_t tile = max_tile;
-        if (data_words > 0) {
-            static const int fit_pct = [] { const char* e = getenv("VKMR_MAP_FIT"); const int v = e ? atoi(e) : 0; return (v < 50 || v > 100) ? 0 : v; }();   // experiments only
-            const double r = (double)stage_words * (double)count / (double)data_words;   // strings that fill the area on average
-            const double want = fit_pct ? r * fit_pct / 100.0 : r * (1.0 - 1.8 / __builtin_sqrt(r > 4.0 ? r : 4.0));
-            const uint64_t fit = want > 0.0 ? (uint64_t)want : 0;
-            if (fit >= max_tile / 4 && fit < tile) tile = (uint32_t)(fit & ~63ull);
-        }
-        // a launch too short to give every CU its two workgroups: smaller tiles, so that it still spreads over the chip
-        const uint32_t spread = (uint32_t)((count / 512u) & ~63u);
-        if (spread < tile) tile = spread < max_tile / 4 ? max_tile / 4 : spread;
-        hipLaunchKernelGGL(kern, dim3((uint32_t)(((uint64_t)count + tile - 1) / tile)), dim3(threads), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-    };
-    // tiles of up to 2048 strings, smaller when the batch is short so that it still
-    // spreads over the chip (>= ~1024 workgroups when it can)
-    uint32_t tile = (count / 1024u) & ~63u;
-    tile = tile < 256u ? 256u : (tile > 2048u ? 2048u : tile);
-    static const int tile_override = [] { const char* e = getenv("VKMR_MAP_TILE"); return e ? atoi(e) : 0; }();   // experiments only
-    if (tile_override >= 64 && tile_override <= 2048) tile = (uint32_t)tile_override & ~63u;
-    const uint32_t grid = (uint32_t)(((uint64_t)count + tile - 1) / tile);   // count + tile can pass 2^32
-    static const int dyn_lds = [] { const char* e = getenv("VKMR_MAP_DYNLDS"); return e ? atoi(e) : 0; }();   // experiments only: caps occupancy
-    auto launch_direct = [&](bool fullfast) {
-        if (fullfast) {
-            if (tile >= 1024u)
-                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, true>), dim3(grid), dim3(512), (size_t)dyn_lds, S(s), data_dev, data_words, meta_dev, count, out, tile);
-            else
-                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, true>), dim3(grid), dim3(256), (size_t)dyn_lds, S(s), data_dev, data_words, meta_dev, count, out, tile);
-        } else {
-            if (tile >= 1024u)
-                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 2, false>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-            else
-                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 2, false>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-        }
-    };
-    switch (variant) {
-        case 1: launch_staged(map_kernel<512, 1024, 16384, 0>, 512, 1024, 16384); break;     // LDS-staged tiles, 64 KiB (round 1's shipped shape)
-        case 2: launch_staged(map_kernel<256, 512, 8192, 0>, 256, 512, 8192); break;         // LDS-staged tiles, 32 KiB
-        case 3: hipLaunchKernelGGL((map_kernel<256, 2048, 5120, 1, true>), dim3(grid), dim3(256), 0, S(s), data_dev, data_words, meta_dev,
-                                   count, out, tile); break;                                 // per-wavefront gather through LDS
-        case 4: launch_direct(avg_words >= 32); break;                                       // per-lane 16-byte loads for every length (round 1's long-string mode)
-        case 6: launch_staged(map_kernel<512, 1024, 17408, 0>, 512, 1024, 17408); break;     // LDS-staged tiles, 68 KiB (two workgroups still fit a CU)
-        case 7: launch_staged(map_kernel<512, 1024, 17664, 0>, 512, 1024, 17664); break;     // LDS-staged tiles, 69 KiB
-        case 8: launch_staged(map_kernel<256, 1024, 17664, 0>, 256, 1024, 17664); break;     // the same tiles by 4 wavefronts instead of 8
-        case 5: hipLaunchKernelGGL((map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words,
-                                   meta_dev, count, out, tile); break;                       // line-aligned loads through a per-lane LDS window
-        default:
-            // Shipped: short strings (< 128 B on average: a cache line holds several) go through
-            // LDS-staged tiles -- HBM traffic == algorithmic bytes; the per-lane mode is 1-2 %
-            // faster but re-reads lines that fell out of L2 (1.6x traffic, profiles/
-            // r01_map_fetch_modes.txt).
-            if (avg_words >= 256 && tile >= 1024u)
-                // very long strings (>= 1 KiB on average), full-size launch: whole 128-byte lines through a per-lane LDS window:
-                // 1.06x instead of 1.46x the algorithmic HBM reads for 1-2 % of time (2.82 vs 2.77 ms on rndm * 4096, warm).
-                // Below 1 KiB the window's per-string start-up shows (5 % at 600 B, 10 % at 200 B on average), and the
-                // per-lane 16-byte loads stay (profiles/r02_long_strings_line_window.txt)
-                hipLaunchKernelGGL((map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>), dim3(grid), dim3(512), 0, S(s), data_dev, data_words,
-                                   meta_dev, count, out, tile);
-            else if (avg_words >= 32)
-                launch_direct(true);   // medium strings, or a short launch (smaller workgroups spread it over the chip)
-            else
-                launch_staged(map_kernel<512, 1024, 17664, 0>, 512, 1024, 17664);
-            break;
+#ifdef VKMR_EXPERIMENTS
+    if (vkmr_map_experiment(S(s), data_dev, data_words, meta_dev, count, out, avg_words)) {
+        g_last_map_mode = MAP_EXPERIMENT;
+        VKMR_TRY(hipGetLastError());
+        return VKMR_OK;
     }
+#endif
+    uint32_t tile = direct_tile(count);
+    if (avg_words >= 256 && tile >= 1024u) {
+        // very long strings (>= 1 KiB on average), full-size launch: 1.06x instead of 1.46x the algorithmic HBM
+        // reads for 1-2 % of time (2.82 vs 2.77 ms on rndm * 4096, warm).  Below 1 KiB the window's per-string
+        // start-up shows (5 % at 600 B, 10 % at 200 B on average): profiles/r02_long_strings_line_window.txt
+        g_last_map_mode = MAP_LINEWIN;
+        hipLaunchKernelGGL((VKMR_MAP_LINEWIN_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+    } else if (avg_words >= 32) {
+        // medium strings, or a short launch (smaller workgroups spread it over the chip)
+        if (tile >= 1024u) {
+            g_last_map_mode = MAP_DIRECT512;
+            hipLaunchKernelGGL((VKMR_MAP_DIRECT512_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        } else {
+            g_last_map_mode = MAP_DIRECT256;
+            hipLaunchKernelGGL((VKMR_MAP_DIRECT256_KERNEL), dim3(tiles_of(count, tile)), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        }
+    } else {
+        // short strings (a cache line holds several): the per-lane mode is 1-2 % faster but re-reads lines that
+        // fell out of L2 (1.6x traffic, profiles/r01_map_fetch_modes.txt)
+        tile = staged_tile(data_words, count, 1024, 17664);
+        g_last_map_mode = MAP_STAGED;
+        hipLaunchKernelGGL((VKMR_MAP_STAGED_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+    }
+    g_last_map_tile = tile;
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
+}
+
+#define VKMR_STR2(x) #x
+#define VKMR_STR(x) VKMR_STR2(x)
+const char* vkmr_hip_kernel_info(void)
+{
+    static thread_local char buf[512];
+    const char* map = "map=(no launch yet; staged: " VKMR_STR((VKMR_MAP_STAGED_KERNEL)) ")";
+    switch (g_last_map_mode) {
+        case MAP_STAGED: map = "map=" VKMR_STR((VKMR_MAP_STAGED_KERNEL)) " LDS-staged tiles sorted by block count"; break;
+        case MAP_DIRECT512: map = "map=" VKMR_STR((VKMR_MAP_DIRECT512_KERNEL)) " per-lane 16-byte loads"; break;
+        case MAP_DIRECT256: map = "map=" VKMR_STR((VKMR_MAP_DIRECT256_KERNEL)) " per-lane 16-byte loads, short launch"; break;
+        case MAP_LINEWIN: map = "map=" VKMR_STR((VKMR_MAP_LINEWIN_KERNEL)) " 128-byte lines through a per-lane LDS window"; break;
+        case MAP_EXPERIMENT: map = "map=EXPERIMENT (VKMR_MAP_VARIANT; not a product build)"; break;
+        default: break;
+    }
+    snprintf(buf, sizeof buf, "%s tile=%u reduce=reduce_pass_kernel(m<=%d)+reduce_collapse_kernel+reduce_tail_kernel(<=%d nodes)", map,
+             g_last_map_tile, VKMR_PASS_MAXM, VKMR_TAIL_MAX);
+    return buf;
 }
 
 // ---- reduce ---------------------------------------------------------------------
@@ -390,7 +417,7 @@ static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32
         g.n_full = n; g.n_last = nl; g.in_stride = in_stride; g.nslices = nslices;
         if (st.kind == STEP_TAIL) {
             g.out_stride = 1;
-            hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(64), 0, stream, in, g, left, roots);
+            hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(vkmr_plan::tail_threads(n)), 0, stream, in, g, left, roots);
             VKMR_TRY(hipGetLastError());
             return VKMR_OK;
         }
@@ -427,7 +454,7 @@ vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s, const vkmr_digest* dig
     if (!digests_dev || !root_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null pointer");
     if (!height_ok(count, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: height does not reduce count to one node");
-    if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
+    if (count > VKMR_TAIL_MAX && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: null scratch");
     VKMR_TRY(hipSetDevice(dev));
     return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), 1, count, count, height,
                          reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
@@ -441,7 +468,7 @@ vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s, const vkmr_digest* dige
     if (!digests_dev || !siblings_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null pointer");
     if (!height_ok(count, height)) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: height does not reduce count to one node");
     if (index >= count) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: index out of range");
-    if (count > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null scratch");
+    if (count > VKMR_TAIL_MAX && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_proof_async: null scratch");
     VKMR_TRY(hipSetDevice(dev));
     const Node* leaves = reinterpret_cast<const Node*>(digests_dev);
     Node* sib = reinterpret_cast<Node*>(siblings_dev);
@@ -475,7 +502,7 @@ vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_dige
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: bad slice geometry");
     if (!height_ok(nslices == 1 ? count_last : capacity, height))
         return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: height does not reduce a slice to one node");
-    if (capacity > 128 && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
+    if (capacity > VKMR_TAIL_MAX && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_slices_async: null scratch");
     VKMR_TRY(hipSetDevice(dev));
     // grid.y carries the slice index: at most 32768 slices per launch sequence; longer runs go in
     // chunks on the same stream (the scratch is reused, the stream serialises them)
