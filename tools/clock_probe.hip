@@ -240,10 +240,17 @@ struct Hwmon {
     std::string power, cap, sclk;
     Hwmon()
     {
-        power = first_glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average");
-        if (power.empty()) power = first_glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input");
-        cap = first_glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap");
-        sclk = first_glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input");
+        // the host has several GPUs: take the hwmon node of the PCI function HIP device 0 sits on
+        char id[64] = "";
+        std::string base = "/sys/class/drm/card*/device/hwmon/hwmon*/";
+        if (hipDeviceGetPCIBusId(id, sizeof id, 0) == hipSuccess && id[0]) {
+            for (char* c = id; *c; ++c) *c = (char)tolower(*c);
+            base = std::string("/sys/bus/pci/devices/") + id + "/hwmon/hwmon*/";
+        }
+        power = first_glob((base + "power1_average").c_str());
+        if (power.empty()) power = first_glob((base + "power1_input").c_str());
+        cap = first_glob((base + "power1_cap").c_str());
+        sclk = first_glob((base + "freq1_input").c_str());
     }
 };
 static double median(std::vector<double> v)

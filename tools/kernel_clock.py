@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vk_merkle_roots_amd.build import STAMPS_LIB  # noqa: E402
 
+if "--lib" in sys.argv:      # another stamped build (e.g. -DVKMR_STAMPS -DVKMR_EXPERIMENTS, with VKMR_MAP_VARIANT in the environment)
+    STAMPS_LIB = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 os.environ["VKMR_HIP_LIB"] = STAMPS_LIB
 import vk_merkle_roots_amd as vk  # noqa: E402
 
@@ -39,8 +41,10 @@ def _first(pattern):
 class Hwmon:
     """Board power (W) and the driver's shader clock (MHz) from sysfs; every field may be missing."""
 
-    def __init__(self):
-        base = "/sys/class/drm/card*/device/hwmon/hwmon*/"
+    def __init__(self, pci_bus_id=None):
+        # the box's host has several GPUs: take the hwmon node of the PCI function HIP device 0 sits on
+        base = f"/sys/bus/pci/devices/{pci_bus_id.lower()}/hwmon/hwmon*/" if pci_bus_id else "/sys/class/drm/card*/device/hwmon/hwmon*/"
+        self.base = base
         self.power = _first(base + "power1_average") or _first(base + "power1_input")
         self.cap = _first(base + "power1_cap")
         self.sclk = _first(base + "freq1_input")
@@ -105,17 +109,26 @@ def main():
     ap.add_argument("--maxlen", type=int, default=127)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--lib", default=None)
     a = ap.parse_args()
     dev = vk.HipDevice(0)
     L = C.CDLL(STAMPS_LIB)
-    hw = Hwmon()
+    pci = None
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+            pci = buf.value.decode()
+    except OSError:
+        pass
+    hw = Hwmon(pci)
     b = vk.rndm_packed(a.seed, 1 << a.leaves_log2, a.maxlen)
     d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * b.count)
     d_scr, d_root = dev.reduce_scratch(b.count), dev.alloc(32)
     height = vk.tree_height(b.count)
     out = {"workload": f"rndm {a.seed} 2^{a.leaves_log2} {a.maxlen}", "library": os.path.relpath(STAMPS_LIB, ROOT),
            "method": "per-workgroup d(s_memtime)/d(s_memrealtime) x 100 MHz after >= %.1f s of back-to-back launches" % a.seconds,
-           "power_cap_W": Hwmon.read(hw.cap, 1e6)}
+           "power_cap_W": Hwmon.read(hw.cap, 1e6), "hwmon": hw.base}
     e0, e1 = dev.new_event(), dev.new_event()
 
     def one(name, tag, launch):

@@ -26,6 +26,7 @@ HOST_LIB = os.path.join(PKG, "libvkmr_host.so")
 STAMPS_LIB = os.path.join(PKG, "libvkmr_hip_stamps.so")
 EXP_LIB = os.path.join(ROOT, "build", "ab", "libexp.so")
 ARCH = "gfx950"
+SPLIT_ADD3_EVERY = 4   # isa_prio_pass: every 4th v_add3_u32 becomes two v_add_u32 (balances the two issue slots: -1.4 %, profiles/r03_ab_add3_split.txt)
 PRIO_GAP = 0    # isa_prio_pass: complex-instruction runs separated by at most this many simple instructions are merged
 
 
@@ -67,7 +68,7 @@ def _llvm(tool):
     raise RuntimeError(f"{tool} not found under /opt/rocm/lib/llvm/bin")
 
 
-def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP):
+def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, split_every=SPLIT_ADD3_EVERY):
     """hipcc in five explicit steps so that the issue-priority pass (isa_prio_pass.py) can run on the device assembly:
     device code -> .s, pass, assemble + link the code object, bundle it, compile the host side around that bundle.
     prio_gap None = plain one-step hipcc build (no pass), for A/B timing."""
@@ -88,7 +89,7 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP):
     from . import isa_prio_pass
     with open(dev_s) as f:
         lines = f.readlines()
-    out, stats = isa_prio_pass.transform(lines, prio_gap)
+    out, stats = isa_prio_pass.transform(lines, prio_gap, prio_level, split_every)
     with open(prio_s, "w") as f:
         f.writelines(out)
     _run([_llvm("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", prio_s, "-o", dev_o])

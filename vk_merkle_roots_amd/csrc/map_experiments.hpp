@@ -54,6 +54,8 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
         case 9: launch_staged(map_kernel<512, 1024, 17600, 0, false, 1>, 512, 1024, 17600); break;   // shipped shape, K[64] read from LDS
         case 10: launch_staged(map_kernel<512, 1024, 17600, 0, false, 2>, 512, 1024, 17600); break;  // K and the schedule ring in LDS (one workgroup per CU)
         case 11: launch_staged(map_kernel<512, 1024, 17600, 0, false, 0>, 512, 1024, 17600); break;  // control for 9/10: same staging, shipped compression
+        case 12: launch_staged(map_kernel<1024, 1024, 17664, 0>, 1024, 1024, 17664); break;  // 16 wavefronts per tile: two workgroups = 8 wavefronts per SIMD
+        case 13: launch_staged(map_kernel<1024, 2048, 34816, 0>, 1024, 2048, 34816); break;  // one 1024-lane workgroup per CU, 136 KiB tiles of 2048 strings
         default:
             // the shipped choice, under the FIT / TILE / DYNLDS knobs
             if (avg_words >= 256 && tile >= 1024u) launch_window();

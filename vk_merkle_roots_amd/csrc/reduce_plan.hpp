@@ -12,7 +12,8 @@
 #define VKMR_PASS_WAVES 4   // waves per workgroup in reduce_pass_kernel (2: 6 % slower, 8: the same -- profiles/r02_reduce_pass_shape.txt)
 #endif
 #ifndef VKMR_PASS_MAXM
-#define VKMR_PASS_MAXM 4    // a wave consumes up to 2^4 chunks of 128 nodes: 5 levels per pass (2^5: 1 % slower)
+#define VKMR_PASS_MAXM 3    // a wave consumes up to 2^3 chunks of 128 nodes: 4 levels per pass.  LDS for the pending halves is 2 KiB per level and wavefront:
+                            // 3 levels = 6 wavefronts per SIMD, 4 = 5; with the issue-priority pass occupancy pays (4.60 vs 4.80 ms per 2^26, profiles/r03_ab_occupancy.txt)
 #endif
 
 #ifndef VKMR_TAIL_MAX

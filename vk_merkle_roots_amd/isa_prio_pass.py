@@ -61,8 +61,58 @@ def classify(line):
     return "C"
 
 
-def transform(lines, gap=0):
-    out, stats = [], {"runs": 0, "complex": 0, "simple_inside": 0, "kernels": 0}
+_ADD3 = re.compile(r"^(\s+)v_add3_u32\s+(v\d+),\s*([^,]+),\s*([^,]+),\s*([^,\s]+)\s*$")
+
+
+def split_add3(lines, every):
+    """Balance the two issue slots: v_add3_u32 is a complex instruction, two v_add_u32 are simple ones.  The node hash has
+    2 108 complex and 1 500 simple instructions, i.e. the complex slot is the longer queue; every add3 that is split moves
+    one instruction from it to the other.  `every` = k splits every k-th v_add3_u32 of each kernel (0 = none).
+    d = a + b + c  ->  d = p + q ; d = r + d   with r != d, d allowed among p, q, and a VGPR in the VOP2 src1 position."""
+    if not every:
+        return lines, 0
+    out, n, done = [], 0, 0
+    isv = lambda x: re.fullmatch(r"v\d+", x) is not None   # noqa: E731
+    for ln in lines:
+        if _LABEL.match(ln) and not ln.startswith(".L"):
+            n = 0
+        m = _ADD3.match(ln.split(";")[0].rstrip() if ";" in ln else ln.rstrip("\n"))
+        if not m:
+            out.append(ln)
+            continue
+        n += 1
+        if n % every:
+            out.append(ln)
+            continue
+        ind, d, a, b, c = m.group(1), m.group(2), m.group(3).strip(), m.group(4).strip(), m.group(5).strip()
+        srcs = [a, b, c]
+        pick = None
+        for ri in (2, 1, 0):
+            r = srcs[ri]
+            p, q = [srcs[k] for k in range(3) if k != ri]
+            if r == d or (srcs.count(d) > 1):
+                continue
+            if not (isv(p) or isv(q)):
+                continue
+            nonv = [x for x in (p, q, ) if not isv(x)]
+            if len(nonv) > 1:
+                continue
+            x, y = (p, q) if isv(q) else (q, p)       # y: the VGPR that goes into src1
+            pick = (x, y, r)
+            break
+        if pick is None:
+            out.append(ln)
+            continue
+        x, y, r = pick
+        out.append(f"{ind}v_add_u32_e32 {d}, {x}, {y}\n")
+        out.append(f"{ind}v_add_u32_e32 {d}, {r}, {d}\n")
+        done += 1
+    return out, done
+
+
+def transform(lines, gap=0, level=1, split_every=0):
+    lines, nsplit = split_add3(lines, split_every)
+    out, stats = [], {"runs": 0, "complex": 0, "simple_inside": 0, "kernels": 0, "add3_split": nsplit}
     in_text = False
     base_prio = 0
     i, n = 0, len(lines)
@@ -106,7 +156,7 @@ def transform(lines, gap=0):
         stats["runs"] += 1
         stats["complex"] += sum(1 for x in run if classify(x) == "C")
         stats["simple_inside"] += sum(1 for x in run if classify(x) == "S")
-        out.append("\ts_setprio 1\n")
+        out.append(f"\ts_setprio {level}\n")
         out.extend(run)
         out.append("\ts_setprio 0\n")
         i = last_c + 1
