@@ -19,11 +19,13 @@ run FAILS; it never reports a smaller N or another transport as if it were the r
 
 Prints ONE JSON line on rank 0 (see the driver contract): `value` is whole-job leaf hashes/s;
 `roofline` prices the dominant kernel (map) against HBM (the spec'd bound), `roofline_reduce`
-the reduction, `valu_roofline` carries the int32-VALU bound the path actually sits under;
+the reduction, `valu_roofline` carries the bound the path actually sits under -- VALU issue: the
+shader clock each kernel HOLDS, measured in-kernel in this run, and the dual-issue floor of its
+instruction stream (static counts of the loaded library);
 `root_matches_golden` checks the timed path's root (and every rank's sub-root) against
 tests/golden/big_roots.json, which holds what the reference's own CPU path printed for these
 streams; `cpu_baseline` is that CPU path (oracle/_ref, built from the reference sources) timed
-on a bounded prefix of the same stream on this box's host cores; `long_strings` is the map
+on the SAME 2^26-string stream on this box's host cores (one core: the path is serial; ~80 s); `long_strings` is the map
 kernel on `rndm 42 2^21 4096` (BASELINE configs[4]'s shape, one 4.3 GB batch).
 """
 import argparse
@@ -41,9 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0            # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T int32 lane-ops/s
-# full-rate issue slots of the shipped code (static counts, tools/isa_count.py)
-SLOTS_BLOCK, SLOTS_DIGEST, SLOTS_NODE = 2532, 2093, 5685
+SIMDS = 256 * 4                   # 256 CUs x 4 SIMDs; one VALU issue turn = 4 shader cycles
+MAX_CLOCK_GHZ = 2.4
 
 
 def parse():
@@ -60,7 +61,9 @@ def parse():
                    help="strings per map launch (default: leaves-log2, the GPU's whole share as ONE packed batch -- 4.4 GB, well inside "
                         "the format's 2^32 words; the reference's Vulkan-sized batches hold <= 2^23, which costs 3 %% in launch tails)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-log2", type=int, default=24, help="prefix of the stream given to the CPU baseline (2^24: about 20 s)")
+    p.add_argument("--cpu-sample-log2", type=int, default=None,
+                   help="give the CPU baseline only the first 2^k strings of the stream (default: the whole stream, about 80 s for 2^26)")
+    p.add_argument("--no-clock-leg", action="store_true", help="skip the in-kernel shader-clock measurement (a child process on the stamped twin of the library)")
     p.add_argument("--levels-variant", action="store_true", help="use the one-level-per-launch reduction")
     p.add_argument("--rehearse-gloo", action="store_true",
                    help="N > 1 on a box with fewer GPUs: ranks share GPU 0 and the roots travel over gloo.  A plumbing "
@@ -120,14 +123,17 @@ def launch_ranks(a):
 # ---- CPU baseline --------------------------------------------------------------------------------
 
 def cpu_baseline(seed, maxlen, sample_log2, full_log2):
-    """The reference CPU-serial path (oracle/_ref/vkmr_cpu_ref: the reference's own
-    SHA-256plus/Inputs/StopWatch sources, g++ -O2) on the first 2^sample_log2 strings
-    of the same rndm stream, timed by its own stopwatch line (reference Vkmr.cpp:55).
-    Falls back to the C restatement ("port") when the reference build is absent."""
+    """The reference CPU-serial path (oracle/_ref/vkmr_cpu_ref: the reference's own SHA-256plus / Inputs / StopWatch
+    sources, g++ -O2) on the same rndm stream through stdin, timed by its own stopwatch line, which spans reading,
+    hashing and the tree (reference Vkmr.cpp:36-55).  By default the WHOLE stream (2^full_log2 strings); with
+    --cpu-sample-log2 a stated prefix, never extrapolated.  Falls back to the C restatement ("port") when the
+    reference build is absent."""
     n = 1 << sample_log2
     rndm = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "rndm")
     ref = os.path.join(ROOT, "oracle", "_ref", "vkmr_cpu_ref")
-    sample = f"first 2^{sample_log2} strings of rndm {seed} * {maxlen} via stdin"
+    whole = sample_log2 == full_log2
+    sample = (f"the whole stream, rndm {seed} 2^{sample_log2} {maxlen}, via stdin" if whole
+              else f"PREFIX: the first 2^{sample_log2} of the 2^{full_log2} strings of rndm {seed} * {maxlen}, via stdin")
     if os.path.exists(ref) and os.path.exists(rndm):
         gen = subprocess.Popen([rndm, str(seed), str(n), str(maxlen)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         out = subprocess.run([ref], stdin=gen.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
@@ -135,14 +141,10 @@ def cpu_baseline(seed, maxlen, sample_log2, full_log2):
         line = [l for l in out.splitlines() if "computed root" in l]
         if line:
             ms = float(line[0].rsplit(" in ", 1)[1])
-            rate = n / (ms / 1e3)
-            return {"value": rate, "unit": "leaf hashes/s", "cores": 1, "kind": "reference",
-                    "sample": sample + " (stdin parse + hash + tree, program's own stopwatch; g++ -O2)",
-                    "host_cores": os.cpu_count(), "seconds": ms / 1e3,
-                    "extrapolated_full_workload_s": (1 << full_log2) / rate,
-                    "extrapolation": f"2^{full_log2} leaves at the sample's rate (the path is linear in the leaf count: one pass over stdin, "
-                                     f"N leaf hashes, N-1 node hashes; tests/golden/big_roots.json records 232-264 s for the full stream "
-                                     f"on the build container)"}
+            root = line[0].split("=> ")[1].split(" in ")[0]
+            return {"value": n / (ms / 1e3), "unit": "leaf hashes/s", "cores": 1, "kind": "reference",
+                    "sample": sample + " (stdin parse + hash + tree, the program's own stopwatch; g++ -O2)",
+                    "host_cores": os.cpu_count(), "seconds": ms / 1e3, "leaves": n, "root": root}
     # port: the oracle library on a packed sample (checker timed as a baseline, never shipped)
     import vk_merkle_roots_amd as vk
     so = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -158,70 +160,35 @@ def cpu_baseline(seed, maxlen, sample_log2, full_log2):
     L.oracle_root_inplace(C.c_void_p(leaves.ctypes.data), C.c_size_t(n), C.c_void_p(root.ctypes.data))
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "leaf hashes/s", "cores": 1, "kind": "port",
-            "sample": sample.replace("via stdin", "packed") + " (hash + tree only)", "host_cores": os.cpu_count(), "seconds": dt,
-            "extrapolated_full_workload_s": (1 << full_log2) / (n / dt), "extrapolation": f"2^{full_log2} leaves at the sample's rate"}
+            "sample": sample.replace("via stdin", "packed") + " (hash + tree only)", "host_cores": os.cpu_count(), "seconds": dt, "leaves": n}
 
 
 # ---- secondary measurements (N = 1 only, outside the timed region) ---------------------------------
 
-def pipeline_rate(dev, vk, batch, nbatches, bstr, cap, nslices, slice_height, tree_height, steps=3):
-    """Pipeline-level rate (SURVEY.md 8d ii): packed batches in PINNED host memory -> root, H2D copies
-    on a copy stream overlapped with the map kernels on the compute stream (two HBM landing zones),
-    then the reduction and the combine.  PCIe-inclusive; reported beside `value`, never as it."""
-    n = batch.count
-    subs = [batch.slice(b * bstr, (b + 1) * bstr) for b in range(nbatches)]
-    pinned = []
-    for sub in subs:
-        pd, pm = C.c_void_p(), C.c_void_p()
-        vk.check(dev.lib.vkmr_hip_host_alloc(max(sub.words * 4, 4), C.byref(pd)), "host_alloc")
-        vk.check(dev.lib.vkmr_hip_host_alloc(sub.count * 8, C.byref(pm)), "host_alloc")
-        C.memmove(pd.value, sub.data.ctypes.data, sub.words * 4)
-        C.memmove(pm.value, sub.meta.ctypes.data, sub.count * 8)
-        pinned.append((pd.value, pm.value, sub.words))
-    zmax = max(w for _, _, w in pinned)
-    zones = [(dev.alloc(zmax * 4), dev.alloc(bstr * 8)) for _ in range(2)]
-    d_digests = dev.alloc(32 * n)
-    d_roots = dev.alloc(32 * nslices)
-    d_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_slices_scratch_bytes(cap, nslices))
-    d_top = dev.alloc(dev.lib.vkmr_hip_reduce_scratch_bytes(max(nslices, 2)) + 64)
-    d_final = dev.alloc(32)
-    copy_stream = dev.new_stream()
-    ev_copied = [dev.new_event() for _ in range(2)]
-    ev_mapped = [dev.new_event() for _ in range(2)]
-    final = np.zeros(8, dtype=np.uint32)
-
-    def run():
-        for b, (pd, pm, words) in enumerate(pinned):
-            z = b & 1
-            zd, zm = zones[z]
-            if b >= 2:   # the landing zone is free once the map that read it has finished
-                vk.check(dev.lib.vkmr_hip_stream_wait_event(dev.index, copy_stream, ev_mapped[z]), "wait")
-            vk.check(dev.lib.vkmr_hip_memcpy_h2d_async(dev.index, copy_stream, zd.ptr, pd, words * 4), "h2d")
-            vk.check(dev.lib.vkmr_hip_memcpy_h2d_async(dev.index, copy_stream, zm.ptr, pm, bstr * 8), "h2d")
-            dev.record(ev_copied[z], copy_stream)
-            vk.check(dev.lib.vkmr_hip_stream_wait_event(dev.index, dev.stream, ev_copied[z]), "wait")
-            dev.map_async(zd, words, zm, bstr, d_digests, out_offset_digests=b * bstr)
-            dev.record(ev_mapped[z])
-        dev.reduce_slices_async(d_digests, nslices, cap, cap, slice_height, d_scratch, d_roots)
-        src = d_roots
-        if nslices > 1:
-            dev.combine_async(d_roots, nslices, d_top, d_final)
-            src = d_final
-        vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, src.ptr, 32), "d2h")
-        dev.sync()
-        dev.sync(copy_stream)
-
-    run()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
-    dt = (time.perf_counter() - t0) / steps
-    for pd, pm, _ in pinned:
-        dev.lib.vkmr_hip_host_free(pd)
-        dev.lib.vkmr_hip_host_free(pm)
-    for b in (d_digests, d_roots, d_scratch, d_top, d_final, zones[0][0], zones[0][1], zones[1][0], zones[1][1]):
-        b.free()
-    return {"leaf_hashes_per_s": n / dt, "ms": dt * 1e3, "h2d_GBps": (batch.words * 4 + n * 8) / dt / 1e9, "root": final.copy()}
+def pipeline_rate(vk, batch, bstr, slice_log2, device=0, runs=3):
+    """Pipeline-level rate (SURVEY.md 8d ii): packed batches in PINNED host memory -> root, on the PRODUCT's schedule:
+    libvkmr_pipeline.so stages the strings into the C++ stream processor's own pinned batches (untimed), then runs what
+    `vkmr hip:<n>` runs -- per batch Mappings::Map (two H2D copies on the device's copy stream, the map kernel behind
+    them on its map stream), slices to Reductions as they fill, the combine of the slice roots.  PCIe-inclusive;
+    reported beside `value`, never as it."""
+    from vk_merkle_roots_amd.build import PIPELINE_LIB
+    L = C.CDLL(PIPELINE_LIB)
+    L.vkmr_host_pipeline_packed.restype = C.c_int
+    L.vkmr_host_pipeline_packed.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p,
+                                            C.POINTER(C.c_double)]
+    best, root = None, None
+    times = []
+    for _ in range(runs + 1):          # the first run also pays for pinning the pool's buffers' first touch
+        hexbuf, secs = C.create_string_buffer(65), C.c_double()
+        rc = L.vkmr_host_pipeline_packed(device, batch.data.ctypes.data, batch.words, batch.meta.ctypes.data, batch.count, bstr, slice_log2,
+                                         hexbuf, C.byref(secs))
+        if rc != 0:
+            raise RuntimeError("vkmr_host_pipeline_packed failed: " + vk._abi.what_error())
+        times.append(secs.value)
+        root = hexbuf.value.decode()
+    dt = float(np.median(times[1:]))
+    return {"leaf_hashes_per_s": batch.count / dt, "ms": dt * 1e3, "h2d_GBps": (batch.words * 4 + batch.count * 8) / dt / 1e9, "root_hex": root,
+            "runs_ms": [t * 1e3 for t in times]}
 
 
 def two_stream_rate(dev, vk, d_batch, bstr, n, slice_height, steps=8):
@@ -284,21 +251,20 @@ def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=10):
     sizes = b.meta[:, 1].astype(np.int64)
     blocks = int(((sizes + 8) // 64 + 1).sum())
     nbytes = b.words * 4 + 40 * n
-    ops = blocks * SLOTS_BLOCK + n * SLOTS_DIGEST
+    info = dev.lib.vkmr_hip_kernel_info().decode()
     for buf in (d_data, d_meta, d_out):
         buf.free()
-    traffic = None   # HBM bytes per launch from the PMC passes over the same workload (tools/gpu_measurement_set.sh -> profiles/pmc_latest.json)
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if rec.get("long_strings_workload") == f"rndm {seed} 2^{count_log2} {maxlen}, one batch" and not os.environ.get("VKMR_MAP_VARIANT"):
-            traffic = rec.get("long_strings_map_hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    # HBM bytes per launch from the PMC passes over the same workload AND the same build of the same kernel
+    from vk_merkle_roots_amd import provenance
+    rec = provenance.load_pmc()
+    traffic, tsrc = provenance.traffic_from_pmc(dict(rec or {}, map_kernel_symbol=(rec or {}).get("long_strings_map_kernel_symbol")), info,
+                                                "long_strings_map_hbm_bytes_per_launch", long_strings_workload=f"rndm {seed} 2^{count_log2} {maxlen}, one batch")
     return {"workload": f"rndm {seed} 2^{count_log2} {maxlen}, one batch", "strings": n, "input_bytes": int(b.words * 4), "map_ms": ms,
+            "map_mode": info.split(" reduce=")[0],
             "leaf_hashes_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "kernel": "map_kernel (line-window mode)", "achieved": nbytes / (ms * 1e-3) / 1e9,
                                                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                               "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes)},
-            "valu_achieved_tops": ops / (ms * 1e-3) / 1e12, "compressions_per_string": blocks / n + 1}
+                                                               "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": int(nbytes)},
+            "blocks": blocks, "compressions_per_string": blocks / n + 1}
 
 
 def hip_all_check(timeout_s=120):
@@ -336,6 +302,58 @@ def hip_all_check(timeout_s=120):
                 "root_matches_golden": root == want, "root": root, "seconds": time.perf_counter() - t0}
     except Exception as e:   # a probe must not take the bench line down with it
         return {"ran": False, "root_matches_golden": None, "error": repr(e)[:200]}
+
+
+def static_counts():
+    """VALU instruction counts of the hash blocks of the library actually loaded (written beside it by the build from the
+    assembly that was assembled into it: vk_merkle_roots_amd/isa_prio_pass.py: hash_blocks)."""
+    from vk_merkle_roots_amd.build import HIP_LIB
+    path = os.path.splitext(os.environ.get("VKMR_HIP_LIB", HIP_LIB))[0] + ".isa.json"
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    hb = rec.get("hash_blocks", {})
+    node = next((v[0] for k, v in hb.items() if "reduce_pass_kernel" in k and v), None)
+    out = {"build": rec.get("build"), "file": os.path.relpath(path, ROOT), "node": node, "map": {}}
+    for k, v in hb.items():
+        if "map_kernel" in k and len(v) >= 2:
+            m = k.split("map_kernelILi")[1].split("EEv")[0].replace("ELi", ", ").replace("ELb", ", ")
+            out["map"][m] = {"block": v[0], "digest": v[1]}
+    return out
+
+
+def clock_leg(seed, maxlen, leaves_log2=24):
+    """The shader clock map_kernel and reduce_pass_kernel HOLD, measured in-kernel (s_memtime against the constant-rate
+    s_memrealtime, per workgroup, after 2 s of back-to-back launches) by tools/kernel_clock.py in a child process on
+    the stamped twin of the library (same source, -DVKMR_STAMPS; in the product no stamp executes)."""
+    tool = os.path.join(ROOT, "tools", "kernel_clock.py")
+    try:
+        r = subprocess.run([sys.executable, tool, "--leaves-log2", str(leaves_log2), "--maxlen", str(maxlen), "--seed", str(seed)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, env={k: v for k, v in os.environ.items() if k != "VKMR_HIP_LIB"})
+        rec = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:   # the leg must not take the bench line down with it
+        return {"error": repr(e)[:200]}
+    return {"method": rec.get("method"), "workload": rec.get("workload"), "library": rec.get("library"), "max_GHz": MAX_CLOCK_GHZ,
+            "power_cap_W": rec.get("power_cap_W"),
+            "map_kernel": {k: rec["map_kernel"].get(k) for k in ("GHz_median", "GHz_p5", "GHz_p95", "board_power_W", "sclk_sysfs_MHz", "phase_share")},
+            "reduce_pass_kernel": {k: rec["reduce_pass_kernel"].get(k) for k in ("GHz_median", "GHz_p5", "GHz_p95", "board_power_W", "sclk_sysfs_MHz")}}
+
+
+def issue_block(units, valu_per_unit, turns_per_unit, ms, clock_ghz):
+    """One kernel against the dual-issue floor: `units` hashes (leaves or nodes) spread over all SIMDs, 64 per wavefront
+    instruction; a turn is 4 shader cycles and takes at most two VALU instructions, one of them a simple one."""
+    per_simd = units / 64.0 / SIMDS
+    out = {"units": int(units), "valu_instr_per_unit": valu_per_unit, "floor_turns_per_unit": turns_per_unit, "ms": ms,
+           "floor_ms_at_max_clock": per_simd * turns_per_unit * 4 / (MAX_CLOCK_GHZ * 1e6)}
+    if clock_ghz:
+        cycles = ms * clock_ghz * 1e6
+        out.update(clock_GHz=clock_ghz, cycles_per_valu_instr=cycles / (per_simd * valu_per_unit),
+                   floor_cycles_per_valu_instr=4.0 * turns_per_unit / valu_per_unit,
+                   floor_ms_at_measured_clock=per_simd * turns_per_unit * 4 / (clock_ghz * 1e6),
+                   frac_of_floor=per_simd * turns_per_unit * 4 / cycles)
+    return out
 
 
 def golden_big_roots(leaves_log2, maxlen):
@@ -582,21 +600,15 @@ def main():
         red_achieved = red_bytes / (red_step_ms * 1e-3) / 1e9
         sizes = batch.meta[:, 1].astype(np.int64)
         blocks = int(((sizes + 8) // 64 + 1).sum())
-        map_ops = blocks * SLOTS_BLOCK + n * SLOTS_DIGEST
-        red_ops = (n - 1) * SLOTS_NODE
-        # HBM bytes per launch from the PMC passes of the SAME launch shape (profiles/pmc_latest.json,
-        # written by tools/pmc_profile.sh + tools/pmc_to_json.py on the GPU box); null when none matches
-        traffic = red_traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("strings_per_map_launch") == bstr and rec.get("maxlen") == a.maxlen and not os.environ.get("VKMR_MAP_VARIANT"):
-                    traffic = rec.get("map_kernel_hbm_bytes_per_launch")
-                    if rec.get("slice_log2") == slice_log2:
-                        red_traffic = rec.get("reduce_hbm_bytes_per_step")
-            except Exception:
-                traffic = None
+        kernel_info = dev.lib.vkmr_hip_kernel_info().decode()
+        # HBM bytes per launch from the PMC passes of the SAME launch shape, the SAME kernel instantiation and the SAME
+        # build of the kernel sources (profiles/pmc_latest.json, tools/pmc_profile.sh + tools/pmc_to_json.py on the
+        # GPU box); null with the reason otherwise
+        from vk_merkle_roots_amd import provenance
+        pmc = provenance.load_pmc()
+        traffic, traffic_src = provenance.traffic_from_pmc(pmc, kernel_info, "map_kernel_hbm_bytes_per_launch", strings_per_map_launch=bstr, maxlen=a.maxlen)
+        red_traffic, red_traffic_src = provenance.traffic_from_pmc(pmc, kernel_info, "reduce_hbm_bytes_per_step", strings_per_map_launch=bstr, maxlen=a.maxlen,
+                                                                   slice_log2=slice_log2)
         out = {
             "metric": "leaf hashes/sec (SHA-256d) + Merkle-root wall time, 2^26 leaves, 1/2/4/8 GPU",
             "value": value, "unit": "leaf hashes/s",
@@ -612,7 +624,8 @@ def main():
                        "gather": (None if dist is None else ("vkmr_hip_gather_roots_async: 1 ncclAllGather of 32 B per rank (C ABI, librccl)" if comm is not None
                                                              else "torch.distributed gather over gloo (rehearsal)")),
                        "bytes_gathered_per_step": (32 * world if dist is not None else 0),
-                       "kernels": dev.lib.vkmr_hip_kernel_info().decode(), "reduce_variant": "levels" if a.levels_variant else "wave"},
+                       "kernels": kernel_info, "reduce_variant": "levels" if a.levels_variant else "wave",
+                       "rccl": dev.lib.vkmr_hip_comm_info().decode()},
             "root": root_hex,
             "sub_roots": sub_roots,
             "root_matches_golden": root_ok,
@@ -620,73 +633,109 @@ def main():
             "golden": "tests/golden/big_roots.json (reference CPU path on the same rndm streams)" if golden else None,
             "merkle_root_wall_ms": ms_per_step,
             "roofline": {"bound": "hbm", "kernel": "map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": map_launch_ms, "algorithmic_bytes_per_launch": map_bytes},
             "roofline_reduce": {"bound": "hbm", "kernel": "reduce_pass_kernel + reduce_collapse_kernel + reduce_tail_kernel (one slice reduction)",
                                 "achieved": red_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": red_achieved / HBM_PEAK_GBPS,
-                                "traffic": red_traffic, "step_ms": red_step_ms, "algorithmic_bytes_per_step": red_bytes},
-            "valu_roofline": {"bound": "int32-valu issue slots (v_alignbit/v_add3/v_perm count 2)", "sustained_tops_measured": 64.0,
-                              "map_ms_per_step": map_launch_ms * nbatches, "reduce_ms_per_step": red_step_ms,
-                              "map_achieved_tops": map_ops / (map_launch_ms * nbatches * 1e-3) / 1e12,
-                              "reduce_achieved_tops": red_ops / (red_step_ms * 1e-3) / 1e12,
-                              "peak_tops": VALU_PEAK_TOPS,
-                              "map_frac": map_ops / (map_launch_ms * nbatches * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                              "reduce_frac": red_ops / (red_step_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS},
+                                "traffic": red_traffic, "traffic_source": red_traffic_src, "step_ms": red_step_ms, "algorithmic_bytes_per_step": red_bytes},
+            "valu_roofline": None,   # filled below (needs the clock leg, which runs after the resident buffers are freed)
             "gather_ms": gather_ms,
             "setup": {"generate_s": t_gen, "h2d_pageable_s": t_h2d},
         }
-        if world == 1 and not a.no_pipeline and not a.levels_variant:
-            pl_bstr = min(n, 1 << 23)   # the stream processor's shape: batches small enough for copies to hide behind kernels
-            pl = pipeline_rate(dev, vk, batch, n // pl_bstr, pl_bstr, cap, nslices, slice_height, tree_height)
-            out["pipeline_pcie_inclusive"] = {"leaf_hashes_per_s": pl["leaf_hashes_per_s"], "ms": pl["ms"], "h2d_GBps": pl["h2d_GBps"],
-                                              "root_matches": digest_hex(pl["root"]) == root_hex,
-                                              "what": "pinned host batches -> async H2D overlapped with map -> reduce -> root"}
         if world == 1 and not a.no_pipeline and not a.levels_variant and nbatches == 1 and nslices == 1 and a.leaves_log2 > 23:
-            # the same step in the reference's shapes -- map launches of 2^23 strings (its batch, Batches.h:131-134), slices of
-            # 2^23 digests (its slice, SHA-256vk.cpp:23) reduced by one batched call, roots combined on the device -- for comparison
-            d_data, words, d_meta = d_batches[0]
+            # the same step in the reference's shapes -- map launches of 2^23 strings (its batch, Batches.h:131-134), each its
+            # OWN packed batch (own data words: the launch picks its fetch mode from them, as a real 2^23-string batch would),
+            # slices of 2^23 digests (its slice, SHA-256vk.cpp:23) reduced by one batched call, roots combined on the device
             sub, ns = 1 << 23, n >> 23
+            subs = []
+            for b in range(ns):
+                sb = batch.slice(b * sub, (b + 1) * sub)
+                subs.append((dev.upload(sb.data), sb.words, dev.upload(sb.meta)))
             d_r8 = dev.alloc(32 * ns)
             d_s8 = dev.alloc(dev.lib.vkmr_hip_reduce_slices_scratch_bytes(sub, ns))
 
             def ref_step():
-                for b in range(ns):
-                    dev.map_async(d_data, words, d_meta, sub, d_digests, out_offset_digests=b * sub, meta_offset=b * sub)
+                for b, (sd, sw, sm) in enumerate(subs):
+                    dev.map_async(sd, sw, sm, sub, d_digests, out_offset_digests=b * sub)
                 dev.reduce_slices_async(d_digests, ns, sub, sub, 23, d_s8, d_r8)
                 dev.combine_async(d_r8, ns, d_top_scratch, d_final)
                 vk.check(dev.lib.vkmr_hip_memcpy_d2h_async(dev.index, dev.stream, final.ctypes.data, d_final.ptr, 32), "d2h")
                 dev.sync()
             ref_step()
+            ref_mode = dev.lib.vkmr_hip_kernel_info().decode().split(" reduce=")[0]
             t0r = time.perf_counter()
             for _ in range(5):
                 ref_step()
             dtr = (time.perf_counter() - t0r) / 5
             out["reference_shapes"] = {"map_launches_per_step": ns, "slices": ns, "ms_per_step": dtr * 1e3, "leaf_hashes_per_s": n / dtr,
-                                       "root_matches": digest_hex(final) == root_hex,
-                                       "what": "batches of 2^23 strings, slices of 2^23 digests (the reference's shapes), same resident input"}
+                                       "root_matches": digest_hex(final) == root_hex, "map_mode": ref_mode,
+                                       "what": "8 packed batches of 2^23 strings (own buffers), slices of 2^23 digests (the reference's shapes), resident input"}
+            for sd, _, sm in subs:
+                sd.free()
+                sm.free()
             d_r8.free()
             d_s8.free()
+            dev.map_async(d_batches[0][0], d_batches[0][1], d_batches[0][2], bstr, d_digests)   # kernel_info reports the main shape again
+            dev.sync()
         if world == 1 and not a.no_pipeline and not a.levels_variant and nbatches == 1 and nslices == 1:
             ts = two_stream_rate(dev, vk, d_batches[0], bstr, n, slice_height)
             out["two_stream_overlap"] = {"leaf_hashes_per_s": ts["leaf_hashes_per_s"], "ms_per_step": ts["ms_per_step"], "what": ts["what"],
                                          "roots_match": all(digest_hex(r) == root_hex for r in ts["roots"])}
-        if world == 1 and not a.no_long_strings:
-            for b_ in d_batches:
+        if world == 1:
+            for b_ in d_batches:    # the resident workload is no longer needed: give the HBM back before the secondary legs
                 b_[0].free()
                 b_[2].free()
             d_digests.free()
+        if world == 1 and not a.no_pipeline and not a.levels_variant:
+            pl_bstr = min(n, 1 << 23)   # the stream processor's shape: batches small enough for copies to hide behind kernels
+            pl = pipeline_rate(vk, batch, pl_bstr, slice_log2 if nslices > 1 else min(slice_log2, 23), device=local_rank)
+            out["pipeline_pcie_inclusive"] = {"leaf_hashes_per_s": pl["leaf_hashes_per_s"], "ms": pl["ms"], "h2d_GBps": pl["h2d_GBps"],
+                                              "root_matches": pl["root_hex"] == root_hex, "runs_ms": pl["runs_ms"],
+                                              "what": "libvkmr_pipeline.so: strings staged in the C++ stream processor's pinned batches, then its own "
+                                                      "schedule -- per batch H2D on the copy stream and the map kernel behind it, slices of 2^23 to "
+                                                      "Reductions as they fill, combine on the device (Mappings::Map / Reductions of `vkmr hip:0`)"}
+        if world == 1 and not a.no_long_strings:
             out["long_strings"] = long_strings_rate(dev, vk, a.seed)
+        # ---- the bound the path sits under: VALU issue at the clock each kernel holds -------------------------------
+        counts = static_counts()
+        clk = None if (a.no_clock_leg or world > 1) else clock_leg(a.seed, a.maxlen)
+        vr = {"bound": "VALU issue: a gfx950 SIMD issues at most two VALU instructions per 4-cycle turn -- one of any kind plus one simple one "
+                       "(add/sub, and/or/xor, shift right, v_bitop3 on VGPRs); floor = max(N / 2, N_complex) turns per hash (DESIGN.md 3)",
+              "static_counts": counts, "clock": clk,
+              "map_ms_per_step": map_launch_ms * nbatches, "reduce_ms_per_step": red_step_ms}
+        if counts and counts.get("node"):
+            mode = provenance.map_symbol_of(kernel_info)
+            key = mode[len("map_kernel<"):-1].replace("false", "0").replace("true", "1") if mode else None   # as the mangled names spell it
+            mc = counts["map"].get(key) if key else None
+            ghz = lambda k: (clk or {}).get(k, {}).get("GHz_median") if clk and "error" not in clk else None   # noqa: E731
+            node = counts["node"]
+            vr["reduce"] = issue_block(n - 1, node["valu"], max(node["valu"] / 2.0, node["complex"]), red_step_ms, ghz("reduce_pass_kernel"))
+            if mc:
+                bpl = blocks / n
+                valu = bpl * mc["block"]["valu"] + mc["digest"]["valu"]
+                cplx = bpl * mc["block"]["complex"] + mc["digest"]["complex"]
+                vr["map"] = issue_block(n, valu, max(valu / 2.0, cplx), map_launch_ms * nbatches, ghz("map_kernel"))
+                vr["map"]["blocks_per_leaf"] = bpl
+        out["valu_roofline"] = vr
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.seed, a.maxlen, min(a.cpu_sample_log2, a.leaves_log2), a.leaves_log2)
-        if world > 1 and comm is not None:
-            out["hip_all_one_process_check"] = hip_all_check()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+            out["cpu_baseline"] = cpu_baseline(a.seed, a.maxlen, a.leaves_log2 if a.cpu_sample_log2 is None else min(a.cpu_sample_log2, a.leaves_log2),
+                                               a.leaves_log2)
+            if out["cpu_baseline"].get("root") and out["cpu_baseline"]["leaves"] == n:
+                out["cpu_baseline"]["root_matches_gpu"] = out["cpu_baseline"]["root"] == root_hex
+    # Every rank leaves the data path together BEFORE rank 0 runs its one-process probe: the other ranks must not sit in
+    # a barrier under the watchdog while rank 0 spends up to two minutes in child processes, and must not tear their
+    # communicators down while it still uses the GPUs.
     enter("teardown")
     if comm is not None:
         dev.lib.vkmr_hip_comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and collective == "nccl":
+            enter("hip:all probe")
+            out["hip_all_one_process_check"] = hip_all_check(timeout_s=60)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     enter("done")
 
 

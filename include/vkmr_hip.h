@@ -260,8 +260,14 @@ VKMR_API void vkmr_hip_digest_hex(const vkmr_digest* d, char* hex);
 
 /* ---- diagnostics ----------------------------------------------------------- */
 VKMR_API const char* vkmr_hip_last_error(void);
-/* Name of the kernel variant a call would launch, for bench/profile bookkeeping. */
+/* What the LAST vkmr_hip_map_async of this process launched (kernel instantiation, fetch mode, tile), the reduction
+ * kernels, and " build=<id>": the identity of the kernel sources and build parameters this library was made from
+ * (vk_merkle_roots_amd/build.py: source_id) -- profile records are matched against it (profiles/pmc_latest.json). */
 VKMR_API const char* vkmr_hip_kernel_info(void);
+/* Which RCCL the communicators are bound to: the shared object ncclAllGather lives in and ncclGetVersion, e.g.
+ * "rccl=/opt/rocm/lib/librccl.so.1 version=22703"; "rccl=not loaded" before the first communicator.  A process that
+ * carries PyTorch must show torch's copy here, not a second one (csrc/comm_rccl.hpp). */
+VKMR_API const char* vkmr_hip_comm_info(void);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ extern "C" {
 
 const char* vkmr_hip_last_error(void) { return g_err; }
 const char* vkmr_hip_kernel_info(void) { return "fake ABI (tests/c/fake_vkmr_hip.cpp): host memory, CPU hashing"; }
+const char* vkmr_hip_comm_info(void) { return "rccl=fake (tests/c/fake_vkmr_hip.cpp)"; }
 
 vkmr_status vkmr_hip_device_count(int* count)
 {

@@ -136,10 +136,56 @@ def test_no_room_for_the_reduction_reserve_is_reported_at_start(fake_vkmr):
 
 
 def test_allocation_failure_with_nothing_in_flight_is_reported(fake_vkmr):
-    """No room for even one slice: Add() refuses, nothing is printed, exit code 0 (reference Vkmr.cpp:44-52)."""
-    r, out, m = run(fake_vkmr, "hip:0", b"a\nb\n", VKMR_SLICE_LOG2=20, VKMR_FAKE_HBM_BYTES=30 << 20)   # the reserve (25 MB of scratch) fits, a 32 MiB slice does not
+    """No room for even the first batch: Add() refuses, nothing is printed, exit code 0 (reference Vkmr.cpp:44-52)."""
+    r, out, m = run(fake_vkmr, "hip:0", b"a\nb\n", VKMR_SLICE_LOG2=20, VKMR_FAKE_HBM_BYTES=30 << 20)   # the default 64 MiB batch does not fit 30 MiB
     assert r.returncode == 0 and m is None
-    assert b"Failed to allocate slice" in r.stderr
+    assert b"Failed to allocate a batch" in r.stderr
+
+
+def test_a_slice_size_that_does_not_fit_is_clamped_with_a_message(fake_vkmr, native, golden):
+    """the slice capacity is derived from the devices (reference Slices<T>::SliceSize, Slices.h:421-454:
+    the largest power of two within the device limits); a VKMR_SLICE_LOG2 beyond what free memory holds is clamped and
+    said so, instead of being discovered by a failed allocation."""
+    s = golden["streams"]["G6_rndm_7_1000_300"]
+    r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), VKMR_SLICE_LOG2=30, VKMR_BATCH_BYTES=65536, VKMR_BATCH_MAX_MB=0, VKMR_FAKE_HBM_BYTES=8 << 20,
+                    VKMR_VERBOSE=1)
+    assert r.returncode == 0 and m and m["root"] == s["root"], r.stderr[-400:]
+    assert b"VKMR_SLICE_LOG2=30 does not fit the device memory" in r.stderr
+    line = [l for l in out if l.startswith("Slices of 2^")]
+    assert line and 1 <= int(line[0].split("2^")[1].split()[0]) < 30 and "clamped" in line[0]
+    # and without the knob: the reference's 2^23, or less when memory is short
+    r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), VKMR_VERBOSE=1)
+    assert m and m["root"] == s["root"] and any(l.startswith("Slices of 2^23 digests (the reference's 256 MiB slice") for l in out)
+    r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), VKMR_VERBOSE=1, VKMR_BATCH_BYTES=65536, VKMR_BATCH_MAX_MB=0, VKMR_FAKE_HBM_BYTES=8 << 20)
+    line = [l for l in out if l.startswith("Slices of 2^")]
+    assert m and m["root"] == s["root"] and line and int(line[0].split("2^")[1].split()[0]) < 23 and b"does not fit" not in r.stderr
+
+
+def test_hip_all_deals_one_slice_per_device_when_the_input_size_is_known(fake_vkmr, native, oracle, tmp_path):
+    """`vkmr hip:all < file` on an 8-GPU node: no knob, the slice capacity becomes ceil(expected leaves / 8) rounded up to a
+    power of two -- BASELINE's north star shape, one slice per GPU (2^29 leaves -> 2^26 per GPU; here 2^17 -> 2^14)."""
+    tool = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    f = tmp_path / "in.txt"
+    with open(f, "wb") as fh:
+        subprocess.run([tool, "11", str(1 << 17), "127"], stdout=fh, stderr=subprocess.DEVNULL, check=True)
+    want, cnt, nb = oracle.root_of_stream(f.read_bytes())
+    exe, env = fake_vkmr
+    env = dict(env, VKMR_FAKE_DEVICES="8", VKMR_VERBOSE="1", VKMR_BATCH_MB="1")
+    with open(f, "rb") as fh:
+        r = subprocess.run([exe, "hip:all"], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-2000:].decode()
+    out = r.stdout.decode().splitlines()
+    res = [m for m in (LINE.match(l) for l in out) if m]
+    assert res and res[-1].group("root") == want and int(res[-1].group("items")) == cnt
+    line = [l for l in out if l.startswith("Slices of 2^")]
+    assert line and line[0].startswith("Slices of 2^14 digests (one slice per device for about"), line
+    filled = [l for l in out if l.startswith("Slice #") and "has been filled" in l]
+    alloc = [l for l in out if l.startswith("Allocations:")]
+    assert alloc and " for 8 slice(s)" in alloc[0], (alloc, len(filled))
+    # through a pipe the size is unknown: the reference's slice size is used
+    r = subprocess.run([exe, "hip:all"], input=f.read_bytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    out = r.stdout.decode().splitlines()
+    assert any(l.startswith("Slices of 2^23 digests") for l in out) and [m for m in (LINE.match(l) for l in out) if m][-1].group("root") == want
 
 
 @pytest.mark.parametrize("which", range(1, 40, 3))
@@ -241,3 +287,46 @@ def test_merkle_proof_of_a_lone_leaf(fake_vkmr):
     r, out, m = run(fake_vkmr, "hip:0", b"solo\n", VKMR_PROOF_INDEX=0)
     proof = [l for l in out if l.startswith("proof: ")]
     assert len(proof) == 2 and fold_proof(proof) == m["root"]      # a lone leaf is hashed with itself: one level
+
+
+def test_packed_pipeline_entry_point_through_the_stream_processor(native, oracle, tmp_path):
+    """vkmr_host_pipeline_packed (libvkmr_pipeline.so: bench.py's PCIe-inclusive measurement, bindings): pre-packed strings
+    staged into the stream processor's own pinned batches, then Mappings / Reductions / combine as `vkmr hip:<n>` runs
+    them.  Here built against the fake ABI (no sanitizer: it is loaded into a Python child) on 1 and 3 devices, several
+    batch and slice shapes, against the oracle."""
+    out = os.path.join(ROOT, "tests", "_build", "fake_plain")
+    os.makedirs(out, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", CSRC]
+    fake = os.path.join(out, "libvkmr_hip.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-shared", "-fPIC"] + inc +
+                          [os.path.join(ROOT, "tests", "c", "fake_vkmr_hip.cpp"), os.path.join(HOST, "cpu_sha256d.cpp"), "-o", fake])
+    files = ["packed_pipeline.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "batches.cpp", "slices.cpp", "mappings.cpp", "reductions.cpp", "stream_pack.cpp"]
+    lib = os.path.join(out, "libvkmr_pipeline.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-shared", "-fPIC"] + inc + [os.path.join(HOST, f) for f in files] +
+                          ["-o", lib, "-L", out, "-lvkmr_hip", "-Wl,-rpath," + out])
+    code = r'''
+import ctypes as C, sys, json, numpy as np
+sys.path.insert(0, %r)
+import vk_merkle_roots_amd as vk
+L = C.CDLL(%r)
+L.vkmr_host_pipeline_packed.restype = C.c_int
+L.vkmr_host_pipeline_packed.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.POINTER(C.c_double)]
+res = []
+for seed, n, maxlen, per_batch, slice_log2, dev in ((3, 5000, 127, 700, 10, 0), (4, 5000, 127, 5000, 0, 0), (5, 9000, 300, 1000, 11, -1), (6, 100, 40, 7, 3, -1), (7, 1, 9, 1, 0, 0)):
+    b = vk.rndm_packed(seed, n, maxlen)
+    hexbuf = C.create_string_buffer(65); secs = C.c_double()
+    rc = L.vkmr_host_pipeline_packed(dev, b.data.ctypes.data, b.words, b.meta.ctypes.data, b.count, per_batch, slice_log2, hexbuf, C.byref(secs))
+    res.append((seed, n, maxlen, rc, hexbuf.value.decode()))
+print(json.dumps(res))
+''' % (ROOT, lib)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VKMR_") and k != "LD_PRELOAD"}
+    env.update(VKMR_FAKE_DEVICES="3", VKMR_BATCH_MAX_MB="0")
+    r = subprocess.run([os.sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:].decode()
+    import json
+    import vk_merkle_roots_amd as vk
+    from vk_merkle_roots_amd.engine import digest_hex
+    for seed, n, maxlen, rc, root in json.loads(r.stdout.decode().splitlines()[-1]):
+        b = vk.rndm_packed(seed, n, maxlen)
+        want = digest_hex(oracle.root(oracle.leaves_packed(b.data, b.meta)))
+        assert rc == 0 and root == want, (seed, n, maxlen, rc, root, want)

@@ -4,7 +4,7 @@
 # Usage (from the repo root on the box):  bash tools/pmc_profile.sh <tag> [bench args...]
 set -o pipefail
 TAG=${1:-run}; shift
-ARGS=${@:---leaves-log2 26 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-long-strings}
+ARGS=${@:---leaves-log2 26 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-long-strings --no-clock-leg}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT

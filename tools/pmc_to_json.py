@@ -30,7 +30,12 @@ def main():
     for path in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    res = {"source": os.path.basename(a.root.rstrip("/")), "strings_per_map_launch": 1 << a.batch_log2, "maxlen": a.maxlen,
+    build = None
+    try:   # the identity of the kernel library that was profiled (vk_merkle_roots_amd/build.py: source_id)
+        build = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vk_merkle_roots_amd", "libvkmr_hip.isa.json")))["build"]
+    except (OSError, ValueError, KeyError):
+        pass
+    res = {"source": os.path.basename(a.root.rstrip("/")), "build": build, "strings_per_map_launch": 1 << a.batch_log2, "maxlen": a.maxlen,
            "slice_log2": a.slice_log2,
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_profile.sh); read = FETCH_SIZE KiB x 1024 x 2 "
                      "(gfx950 tallies its 128-byte requests as 64 B; calibrated on 1 GiB for both read patterns, tools/fetch_calibrate.hip), "
@@ -50,6 +55,7 @@ def main():
         res[short + "_launches_profiled"] = n
         if short == "map_kernel":
             res["map_kernel_variant"] = k
+            res["map_kernel_symbol"] = k          # e.g. map_kernel<512, 1024, 17664, 0, false, 0>: matched against vkmr_hip_kernel_info()
             steps = n / a.launches_per_step
         if short.startswith("reduce_"):
             red_read += fetch

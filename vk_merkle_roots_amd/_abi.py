@@ -65,6 +65,7 @@ SIGNATURES = {
     "vkmr_hip_digest_hex": (None, [C.c_void_p, C.c_char_p]),
     "vkmr_hip_last_error": (C.c_char_p, []),
     "vkmr_hip_kernel_info": (C.c_char_p, []),
+    "vkmr_hip_comm_info": (C.c_char_p, []),
 }
 
 HOST_SIGNATURES = {

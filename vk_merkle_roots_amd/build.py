@@ -23,6 +23,7 @@ HOST = os.path.join(CSRC, "host")
 BIN = os.path.join(PKG, "bin")
 HIP_LIB = os.path.join(PKG, "libvkmr_hip.so")
 HOST_LIB = os.path.join(PKG, "libvkmr_host.so")
+PIPELINE_LIB = os.path.join(PKG, "libvkmr_pipeline.so")   # the C++ stream processor behind one C entry point (needs libvkmr_hip.so)
 STAMPS_LIB = os.path.join(PKG, "libvkmr_hip_stamps.so")
 EXP_LIB = os.path.join(ROOT, "build", "ab", "libexp.so")
 ARCH = "gfx950"
@@ -68,6 +69,27 @@ def _llvm(tool):
     raise RuntimeError(f"{tool} not found under /opt/rocm/lib/llvm/bin")
 
 
+def source_id(defines=(), prio_gap=PRIO_GAP, split_every=SPLIT_ADD3_EVERY):
+    """Identity of what a kernel library is made from: the device sources, the C ABI header, the issue pass and the
+    build parameters.  Compiled into the library (vkmr_hip_kernel_info: " build=<id>") and recorded beside every
+    profile (profiles/pmc_latest.json), so that a counter record is only ever quoted for the kernels that produced it."""
+    import zlib
+    crc, adl = 0, 1      # two independent 32-bit checksums over the same byte stream: 16 hex digits of identity
+    def feed(b):
+        nonlocal crc, adl
+        crc, adl = zlib.crc32(b, crc), zlib.adler32(b, adl)
+    files = [os.path.join(CSRC, "vkmr_hip.hip")] + _tree(CSRC, (".hpp", ".h")) + [os.path.join(ROOT, "include", "vkmr_hip.h"),
+                                                                                     os.path.join(PKG, "isa_prio_pass.py")]
+    for f in sorted(files):
+        if os.sep + "host" + os.sep in f:
+            continue            # host-side C++ is not in the kernel library
+        feed(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            feed(fh.read())
+    feed(repr((sorted(defines), prio_gap, split_every, ARCH)).encode())
+    return f"{crc & 0xffffffff:08x}{adl & 0xffffffff:08x}"
+
+
 def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, split_every=SPLIT_ADD3_EVERY):
     """hipcc in five explicit steps so that the issue-priority pass (isa_prio_pass.py) can run on the device assembly:
     device code -> .s, pass, assemble + link the code object, bundle it, compile the host side around that bundle.
@@ -77,7 +99,8 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     if not force and _newer(target, deps):
         return target
     os.makedirs(os.path.dirname(target), exist_ok=True)
-    common = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden"] + defines
+    common = (["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden"] + defines +
+              [f'-DVKMR_BUILD_ID="{source_id(defines, prio_gap, split_every)}"'])
     if prio_gap is None:
         _run([_hipcc()] + common + ["-shared", "-Wl,-rpath,/opt/rocm/lib", "-o", target, src])
         return target
@@ -100,6 +123,12 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     _run([_hipcc(), "-shared", "-Wl,-rpath,/opt/rocm/lib", "-o", target, host_o])
     with open(os.path.join(work, "prio_pass_stats.txt"), "w") as f:
         f.write(repr(stats) + "\n")
+    # static instruction counts of the hash blocks, for bench.py's issue roofline; travels with the library
+    import json
+    info = {"build": source_id(defines, prio_gap, split_every), "library": os.path.basename(target), "prio_gap": prio_gap,
+            "split_add3_every": split_every, "pass": stats, "hash_blocks": isa_prio_pass.hash_blocks(out)}
+    with open(os.path.splitext(target)[0] + ".isa.json", "w") as f:
+        json.dump(info, f, indent=1)
     return target
 
 
@@ -148,6 +177,15 @@ def build_host(force=False):
         if need(out, srcs):
             _run([cxx] + flags + ["-o", out] + srcs)
         built.append(out)
+
+    pipe_files = ["packed_pipeline.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "batches.cpp", "slices.cpp", "mappings.cpp", "reductions.cpp",
+                  "stream_pack.cpp"]
+    pipe_srcs = [os.path.join(HOST, f) for f in pipe_files]
+    if all(os.path.exists(s) for s in pipe_srcs):
+        if need(PIPELINE_LIB, pipe_srcs + [HIP_LIB]):
+            _run([cxx] + flags + ["-shared", "-fPIC", "-fvisibility=hidden", "-o", PIPELINE_LIB] + pipe_srcs +
+                 ["-L", PKG, "-lvkmr_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+        built.append(PIPELINE_LIB)
 
     vk_files = ["vkmr_main.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "inputs.cpp", "batches.cpp", "slices.cpp",
                 "mappings.cpp", "reductions.cpp", "stream_pack.cpp"]

@@ -34,8 +34,11 @@ struct Rccl {
     ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
+inline bool g_asked = false;   // rccl() has been called: only then does vkmr_hip_comm_info report on the binding
+
 inline const Rccl& rccl()
 {
+    g_asked = true;
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -158,6 +161,24 @@ vkmr_status vkmr_hip_comm_init_all(const int* devs, int ndev, vkmr_comm* out)
     }
     *out = comm;
     return VKMR_OK;
+}
+
+const char* vkmr_hip_comm_info(void)
+{
+    static thread_local char buf[512];
+    if (!vkmr_comm_detail::g_asked) return "rccl=not loaded";   // asking would load librccl (573 MB) just to describe it
+    const auto& r = vkmr_comm_detail::rccl();
+    if (!r.ok) {
+        snprintf(buf, sizeof buf, "rccl=unusable (%s)", r.why);
+        return buf;
+    }
+    Dl_info info;
+    const char* path = "?";
+    if (dladdr(reinterpret_cast<void*>(r.AllGather), &info) && info.dli_fname) path = info.dli_fname;
+    int ver = 0;
+    if (r.GetVersion) (void)r.GetVersion(&ver);
+    snprintf(buf, sizeof buf, "rccl=%s version=%d", path, ver);
+    return buf;
 }
 
 vkmr_status vkmr_hip_comm_destroy(vkmr_comm c)

@@ -53,6 +53,35 @@ bool Batch::Push(const char* p, size_t n)
     return true;
 }
 
+size_t Batch::PushPacked(const uint32_t* data, const vkmr_metadata* meta, size_t count, size_t max_strings)
+{
+    if (!(*this) || count == 0) return 0;
+    size_t take = count < max_strings ? count : max_strings;
+    if (take > m_cap_count - m_count) take = m_cap_count - m_count;
+    const size_t first = meta[0].start;
+    // the longest prefix whose words fit: strings are consecutive, so the words of [0, k) end where string k - 1 ends
+    auto end_of = [&](size_t k) { return (size_t)meta[k - 1].start + WordCount(meta[k - 1].size) - first; };
+    size_t lo = 0, hi = take;   // invariant: [0, lo) fits
+    while (lo < hi) {
+        const size_t mid = (lo + hi + 1) / 2;
+        if (m_words + end_of(mid) <= m_cap_words && m_words + end_of(mid) <= 0xFFFFFFFFull) lo = mid; else hi = mid - 1;
+    }
+    take = lo;
+    if (take == 0) return 0;
+    const size_t nw = end_of(take);
+    std::memcpy(m_data + m_words, data + first, nw * 4);
+    size_t bytes = 0;
+    for (size_t i = 0; i < take; ++i) {
+        m_meta[m_count + i].start = (uint32_t)(m_words + (meta[i].start - first));
+        m_meta[m_count + i].size = meta[i].size;
+        bytes += meta[i].size;
+    }
+    m_words += nw;
+    m_bytes += bytes;
+    m_count += take;
+    return take;
+}
+
 bool Batch::Push(const std::vector<std::string>& strings)
 {
     if (!(*this)) return false;

@@ -62,6 +62,10 @@ public:
     // and appended (possibly nothing: the caller then falls back to PushLines).  Every part
     // but the last of a final span ends in '\n'.
     struct PackResult PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, class ForkJoin& pool);
+    // Appends strings that are already in the packed layout (consecutive, canonical: string i + 1 starts on the word after
+    // string i): one memcpy of their words, metadata rebased onto this batch.  Takes as many of the `count` strings as fit
+    // (and at most `max_strings`); returns how many.
+    size_t PushPacked(const uint32_t* data, const vkmr_metadata* meta, size_t count, size_t max_strings);
     // Drops the last `count` strings (reference Batch::Pop, src/vkmr/Batches.cpp:123-125).
     void Pop(size_t count);
 

@@ -18,7 +18,12 @@ namespace vkmr {
 HipConfig HipConfig::FromEnv()
 {
     HipConfig c;
-    if (const char* e = getenv("VKMR_SLICE_LOG2")) c.slice_log2 = (uint32_t)atoi(e);
+    if (const char* e = getenv("VKMR_SLICE_LOG2")) {
+        c.slice_log2 = (uint32_t)atoi(e);
+        c.slice_log2_given = true;
+        if (c.slice_log2 < 1) c.slice_log2 = 1;
+        if (c.slice_log2 > 40) c.slice_log2 = 40;   // clamped again to what the devices hold (ChooseSliceLog2)
+    }
     if (const char* e = getenv("VKMR_BATCH_MB")) c.batch_bytes = (size_t)atol(e) << 20;
     if (const char* e = getenv("VKMR_BATCH_BYTES")) c.batch_bytes = (size_t)atol(e);
     if (const char* e = getenv("VKMR_BATCH_MAX_MB")) c.batch_bytes_max = (size_t)atol(e) << 20;
@@ -31,8 +36,6 @@ HipConfig HipConfig::FromEnv()
         const unsigned hw = std::thread::hardware_concurrency();
         c.pack_threads = hw == 0 ? 1u : (hw > 16u ? 16u : hw);
     }
-    if (c.slice_log2 < 1) c.slice_log2 = 1;
-    if (c.slice_log2 > 40) c.slice_log2 = 40;   // beyond HBM: the allocation fails and Add() reports it
     if (c.batch_bytes < 4096) c.batch_bytes = 4096;
     // a packed batch addresses its data by 32-bit word index (vkmr_metadata::start)
     if (c.batch_bytes > (size_t)0xFFFFFFFFull * 4u) c.batch_bytes = (size_t)0xFFFFFFFFull * 4u;
@@ -42,17 +45,20 @@ HipConfig HipConfig::FromEnv()
     return c;
 }
 
-HipSha256D::HipSha256D() : m_count(0)
+int HipSha256D::Count() const
 {
-    int n = 0;
-    if (vkmr_hip_device_count(&n) == VKMR_OK) m_count = n;
+    if (m_count < 0) {
+        int n = 0;
+        m_count = (vkmr_hip_device_count(&n) == VKMR_OK) ? n : 0;
+    }
+    return m_count;
 }
 
 std::vector<ISha256D::name_type> HipSha256D::Available() const
 {
     std::vector<ISha256D::name_type> names;
-    for (int i = 0; i < m_count; ++i) names.push_back("hip:" + std::to_string(i));
-    if (m_count > 1) names.push_back("hip:all");
+    for (int i = 0; i < Count(); ++i) names.push_back("hip:" + std::to_string(i));
+    if (Count() > 1) names.push_back("hip:all");
     return names;
 }
 
@@ -63,9 +69,9 @@ int HipSha256D::IndexOf(const ISha256D::name_type& name) const
 {
     if (name.size() > 4 && name.compare(0, 4, "hip:") == 0 && name.find_first_not_of("0123456789", 4) == std::string::npos) {
         const long i = atol(name.c_str() + 4);
-        return i < m_count ? (int)i : -1;
+        return i < Count() ? (int)i : -1;
     }
-    for (int i = 0; i < m_count; ++i) {
+    for (int i = 0; i < Count(); ++i) {
         char devname[256] = "";
         if (vkmr_hip_device_name(i, devname, sizeof devname) == VKMR_OK && name == devname) return i;
     }
@@ -83,7 +89,8 @@ std::string HipSha256D::Describe(const ISha256D::name_type& name) const
 
 bool HipSha256D::Has(const ISha256D::name_type& name) const
 {
-    if (name == "hip:all") return m_count > 1;
+    if (name == "CPU") return false;   // the other backend's name: no reason to wake the GPU runtime
+    if (name == "hip:all") return Count() > 1;
     return IndexOf(name) >= 0;
 }
 
@@ -91,7 +98,7 @@ std::unique_ptr<HipSha256D::Instance> HipSha256D::Get(const ISha256D::name_type&
 {
     std::vector<int> devs;
     if (name == "hip:all") {
-        for (int i = 0; i < m_count; ++i) devs.push_back(i);
+        for (int i = 0; i < Count(); ++i) devs.push_back(i);
     } else {
         devs.push_back(IndexOf(name));
     }
@@ -99,13 +106,12 @@ std::unique_ptr<HipSha256D::Instance> HipSha256D::Get(const ISha256D::name_type&
 }
 
 HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices, const HipConfig& cfg)
-    : ISha256D(name), m_cfg(cfg), m_slices(devices, (size_t)1 << cfg.slice_log2, cfg.slice_budget ? cfg.slice_budget : cfg.max_inflight + 1), m_ok(true)
+    : ISha256D(name), m_cfg(cfg), m_device_ids(devices), m_ok(true)
 {
     for (int d : devices) {
         PerDevice pd;
         pd.dev = d;
-        m_ok = m_ok && vkmr_hip_stream_create(d, &pd.map_stream) == VKMR_OK &&
-               vkmr_hip_stream_create(d, &pd.reduce_stream) == VKMR_OK;
+        m_ok = m_ok && vkmr_hip_stream_create(d, &pd.map_stream) == VKMR_OK;
         pd.batches.reset(new Batches(d, cfg.batch_bytes));
         if (cfg.verbose) {
             char devname[256] = "";
@@ -119,16 +125,101 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
         }
         m_devs.push_back(std::move(pd));
     }
+    // The first batch needs the map stream only once it is packed, the copy stream with it, the reduce stream when the
+    // first slice is full: the latter two are made on a helper thread while this one starts reading (each hipStreamCreate
+    // is 10-15 ms of a run that takes 150 ms for 2^25 strings: profiles/r02_hip_api_stats_256_slices.csv).
+    m_setup = std::thread([this] {
+        for (auto& pd : m_devs)
+            m_setup_ok = m_setup_ok && vkmr_hip_stream_create(pd.dev, &pd.copy_stream) == VKMR_OK &&
+                         vkmr_hip_stream_create(pd.dev, &pd.reduce_stream) == VKMR_OK;
+    });
     m_pool.reset(new ForkJoin(cfg.pack_threads > 1 ? cfg.pack_threads - 1 : 0));
     m_mappings = Mappings::New(cfg.verbose);
-    m_reductions = Reductions::New(devices, (size_t)1 << cfg.slice_log2, cfg.verbose);
     if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
+    // slices and reductions are made when the first strings arrive: their size is chosen then (EnsureGeometry)
+}
+
+// Digests per slice, as a power of two.  The counterpart of the reference's Slices<T>::SliceSize
+// (src/vkmr/Slices.h:421-454: the largest power of two within the smallest of four device limits and the preferred
+// 256 MiB).  On HIP the only device limit is memory:
+//   fits      what the devices' free memory holds of `budget` resident slices (32 B per digest each) plus the
+//             reduction scratch sets (about 12 B per digest of capacity) beside the batch pipeline's landing zones,
+//             with 15 % left alone;
+//   wanted    VKMR_SLICE_LOG2 when given; else, with several devices and an input of known size (stdin is a regular
+//             file), the leaves that input will hold -- estimated from the average line of the first span -- dealt
+//             one slice per device (the shape BASELINE's north star names); else the reference's 2^23.
+// The result is min(wanted, fits); a given value that does not fit is clamped with a message instead of failing in hipMalloc.
+uint32_t HipSha256D::Instance::ChooseSliceLog2(const char* first_span, size_t len, std::string* why) const
+{
+    size_t free_min = ~(size_t)0;
+    for (int d : m_device_ids) {
+        size_t f = 0, t = 0;
+        if (vkmr_hip_device_mem_info(d, &f, &t) == VKMR_OK && f < free_min) free_min = f;
+    }
+    const size_t budget = m_cfg.slice_budget ? m_cfg.slice_budget : m_cfg.max_inflight + 1;
+    const double landing = (double)(m_cfg.max_inflight + 2) * ((double)m_cfg.batch_bytes * 1.25);   // data + metadata zones of the pipeline
+    double room = (free_min == ~(size_t)0) ? 0.0 : 0.85 * (double)free_min - landing;
+    uint32_t fits = 1;
+    while (fits < 40 && (double)((size_t)1 << (fits + 1)) * (32.0 * (double)budget + 12.0) <= room) ++fits;
+    uint32_t wanted = 23;
+    *why = "the reference's 256 MiB slice (src/vkmr/SHA-256vk.cpp:23)";
+    if (m_cfg.slice_log2_given) {
+        wanted = m_cfg.slice_log2;
+        *why = "VKMR_SLICE_LOG2";
+    } else if (m_device_ids.size() > 1 && m_cfg.expected_input_bytes > 0 && first_span && len > 0) {
+        size_t lines = 0;
+        const size_t look = len < ((size_t)4 << 20) ? len : ((size_t)4 << 20);
+        for (const char* p = first_span; (p = static_cast<const char*>(memchr(p, '\n', (size_t)(first_span + look - p)))) != nullptr; ++p) ++lines;
+        if (lines > 0) {
+            const double avg = (double)look / (double)lines;                        // bytes per line, newline included
+            const double leaves = (double)m_cfg.expected_input_bytes / avg;
+            // the estimate is good to a few percent: a power-of-two stream must not tip into slices twice as large because the
+            // sample's lines were a little short (a few leaves too many simply open one more, nearly empty, slice)
+            const double per_dev = leaves / (double)m_device_ids.size() / 1.03;
+            wanted = 1;
+            while (wanted < 40 && (double)((size_t)1 << wanted) < per_dev) ++wanted;
+            if (wanted < 10) wanted = 10;
+            *why = "one slice per device for about " + std::to_string((unsigned long long)leaves) + " leaves on " + std::to_string(m_device_ids.size()) + " devices";
+        }
+    }
+    if (wanted > fits) {
+        if (m_cfg.slice_log2_given)
+            std::cerr << "VKMR_SLICE_LOG2=" << wanted << " does not fit the device memory (" << (free_min >> 20) << " MiB free, " << budget
+                      << " slices resident): using 2^" << fits << " digests per slice." << std::endl;
+        *why += ", clamped to what device memory holds";
+        wanted = fits;
+    }
+    return wanted;
+}
+
+bool HipSha256D::Instance::EnsureGeometry(const char* first_span, size_t len)
+{
+    if (m_geometry) return m_ok;
+    m_geometry = true;
+    std::string why;
+    m_cfg.slice_log2 = ChooseSliceLog2(first_span, len, &why);
+    if (m_cfg.verbose) std::cout << "Slices of 2^" << m_cfg.slice_log2 << " digests (" << why << ")." << std::endl;
+    const size_t capacity = (size_t)1 << m_cfg.slice_log2;
+    m_slices = Slices(m_device_ids, capacity, m_cfg.slice_budget ? m_cfg.slice_budget : m_cfg.max_inflight + 1);
+    m_reductions = Reductions::New(m_device_ids, capacity, m_cfg.verbose);
     if (!m_reductions->Ok()) m_ok = false;   // reported by Reductions::New
-    if (cfg.proof_index >= 0) m_reductions->RequestProof((uint64_t)cfg.proof_index);
+    if (m_cfg.proof_index >= 0) m_reductions->RequestProof((uint64_t)m_cfg.proof_index);
+    return m_ok;
+}
+
+void HipSha256D::Instance::JoinSetup()
+{
+    if (!m_setup.joinable()) return;
+    m_setup.join();
+    if (!m_setup_ok) {
+        std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
+        m_ok = false;
+    }
 }
 
 HipSha256D::Instance::~Instance()
 {
+    JoinSetup();
     // ops first (they hold batches and slices), then the pools and streams
     m_pool.reset();
     m_mappings.reset();
@@ -138,6 +229,7 @@ HipSha256D::Instance::~Instance()
     for (auto& pd : m_devs) {
         pd.batches.reset();
         vkmr_hip_stream_destroy(pd.dev, pd.map_stream);
+        vkmr_hip_stream_destroy(pd.dev, pd.copy_stream);
         vkmr_hip_stream_destroy(pd.dev, pd.reduce_stream);
     }
 }
@@ -160,7 +252,7 @@ void HipSha256D::Instance::Account(std::vector<Slice>&& retired)
         if (slice.IsFilled()) {
             if (m_cfg.verbose) std::cout << "Slice #" << slice.Number() << " has been filled." << std::endl;
             const int dev = slice.Device();
-            if (m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, Dev(dev).reduce_stream) != VKMR_OK) m_ok = false;
+            if (m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, (JoinSetup(), Dev(dev).reduce_stream)) != VKMR_OK) m_ok = false;
         }
     }
     if (m_mappings->Failed()) m_ok = false;
@@ -215,6 +307,7 @@ bool HipSha256D::Instance::MapCurrent()
     Slice& slice = m_slices.Current();
     if (m_batch.Empty() || !slice) return true;
     if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
+    JoinSetup();   // the copy stream is needed from here on
     PerDevice& pd = Dev(slice.Device());
     AdaptBatchSize(m_batch);
     if (!pd.prefetched && !m_draining && m_batch.Words() * 4 >= pd.batches->DataBytes() / 2) {
@@ -223,7 +316,7 @@ bool HipSha256D::Instance::MapCurrent()
         pd.prefetched = true;
         pd.batches->Prefetch(m_cfg.max_inflight);
     }
-    return m_mappings->Map(std::move(m_batch), slice.Sub(), pd.map_stream) == VKMR_OK;
+    return m_mappings->Map(std::move(m_batch), slice.Sub(), pd.map_stream, pd.copy_stream) == VKMR_OK;
 }
 
 bool HipSha256D::Instance::StartSliceAndBatch()
@@ -246,7 +339,7 @@ bool HipSha256D::Instance::StartSliceAndBatch()
 
 bool HipSha256D::Instance::Add(const char* bytes, size_t size)
 {
-    if (!m_ok) return false;
+    if (!m_ok || !EnsureGeometry(nullptr, 0)) return false;
     // progress of in-flight work is discovered here, on the caller's thread
     // (reference SHA-256vk.cpp:318-335)
     m_reductions->Update();
@@ -287,7 +380,7 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
 // hand-offs as Add().
 bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tally* tally)
 {
-    if (!m_ok) return false;
+    if (!m_ok || !EnsureGeometry(buf, len)) return false;
     size_t pos = 0;
     while (pos < len) {
         m_reductions->Update();
@@ -343,9 +436,73 @@ bool HipSha256D::Instance::GrowBatchesFor(int dev, size_t string_bytes)
     return true;
 }
 
+bool HipSha256D::Instance::StagePacked(const uint32_t* data, const vkmr_metadata* meta, size_t count)
+{
+    if (!m_ok || !EnsureGeometry(nullptr, 0)) return false;
+    auto stage_current = [&] {
+        Slice& slice = m_slices.Current();
+        if (m_batch.Empty() || !slice) return;
+        Staged st;
+        st.dev = slice.Device();
+        st.sub = slice.Sub();
+        st.batch = std::move(m_batch);
+        m_staged.push_back(std::move(st));
+    };
+    size_t pos = 0;
+    while (pos < count) {
+        if (!m_slices.Current()) {
+            if (!StartSliceAndBatch()) return false;
+        } else if (m_slices.Current().Available() == 0) {
+            stage_current();
+            if (!StartSliceAndBatch()) return false;
+        }
+        Slice& slice = m_slices.Current();
+        const size_t took = m_batch.PushPacked(data, meta + pos, count - pos, slice.Available());
+        slice.Reserve(took);
+        pos += took;
+        if (pos >= count) break;
+        if (slice.Available() == 0) continue;
+        if (took == 0) {   // the batch is full: hold it, continue in a fresh one of the same device
+            const int dev = slice.Device();
+            if (m_batch.Empty()) {
+                std::cerr << "A packed string does not fit an empty batch." << std::endl;
+                return false;
+            }
+            stage_current();
+            if (!NewBatch(dev)) return (m_ok = false);
+        }
+    }
+    return true;
+}
+
+ISha256D::out_type HipSha256D::Instance::RootOfStaged()
+{
+    if (!m_ok || !m_geometry) return "";
+    {   // the residual batch joins the staged ones
+        Slice& slice = m_slices.Current();
+        if (!m_batch.Empty() && slice) {
+            Staged st;
+            st.dev = slice.Device();
+            st.sub = slice.Sub();
+            st.batch = std::move(m_batch);
+            m_staged.push_back(std::move(st));
+        }
+    }
+    JoinSetup();
+    for (auto& st : m_staged) {
+        m_reductions->Update();
+        if (m_mappings->InFlight()) Account(m_mappings->Update());
+        if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
+        PerDevice& pd = Dev(st.dev);
+        if (!m_ok || m_mappings->Map(std::move(st.batch), std::move(st.sub), pd.map_stream, pd.copy_stream) != VKMR_OK) return "";
+    }
+    m_staged.clear();
+    return Root();
+}
+
 ISha256D::out_type HipSha256D::Instance::Root()
 {
-    if (!m_ok) return "";
+    if (!m_ok || !m_geometry) return "";   // nothing was ever added: no root (reference CpuSha256D::Root on empty, SHA-256plus.cpp:494-496)
     // residual batch, then every mapping (reference SHA-256vk.cpp:291-299)
     m_draining = true;
     const bool single = m_slices.LastNumber() <= 1;
@@ -362,6 +519,7 @@ ISha256D::out_type HipSha256D::Instance::Root()
         if (!s || s.Count() == 0) continue;
         const uint32_t height = (single && number == 1) ? tree_height(s.Count()) : m_cfg.slice_log2;
         const int dev = s.Device();
+        JoinSetup();
         if (m_reductions->Reduce(std::move(s), height, Dev(dev).reduce_stream) != VKMR_OK) return "";
     }
     const out_type root = m_reductions->WaitFor();

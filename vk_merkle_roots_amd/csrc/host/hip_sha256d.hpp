@@ -9,6 +9,7 @@
 #pragma once
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "isha256d.hpp"
@@ -17,7 +18,13 @@
 namespace vkmr {
 
 struct HipConfig {
-    uint32_t slice_log2 = 23;        // digests per slice: 2^23 = 256 MiB, the reference's slice (SHA-256vk.cpp:23)
+    uint32_t slice_log2 = 0;         // digests per slice as a power of two; 0 = chosen from the devices when the first strings arrive
+                                     // (Instance::ChooseSliceLog2, the counterpart of Slices<T>::SliceSize, src/vkmr/Slices.h:421-454):
+                                     // the reference's 2^23 = 256 MiB (SHA-256vk.cpp:23), or, with several GPUs and an input file of
+                                     // known size, one slice per GPU; never more than the devices' free memory holds.  VKMR_SLICE_LOG2
+                                     // sets it; a value that does not fit is clamped with a message
+    bool slice_log2_given = false;   // slice_log2 came from the caller (VKMR_SLICE_LOG2), not from the default
+    uint64_t expected_input_bytes = 0;  // bytes stdin will deliver when that is known (a regular file), else 0
     size_t batch_bytes = 64u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
                                      // :247-248); fed from stdin, 32-64 MiB batches pipeline best on MI355X (copies
                                      // and kernels hide behind the host packer; measured sweep in DESIGN.md 5)
@@ -40,8 +47,8 @@ class HipSha256D {
 public:
     class Instance;
 
-    HipSha256D();
-    explicit operator bool() const { return m_count > 0; }
+    HipSha256D() = default;          // no HIP call until a device is asked for: `vkmr CPU` never touches the GPU runtime
+    explicit operator bool() const { return Count() > 0; }
     bool Has(const ISha256D::name_type&) const;
     // One use per name, like the reference's Get (SHA-256vk.cpp:224-229).
     std::unique_ptr<Instance> Get(const ISha256D::name_type&, const HipConfig& cfg = HipConfig::FromEnv());
@@ -51,7 +58,8 @@ public:
 
 private:
     int IndexOf(const ISha256D::name_type&) const;   // device index of "hip:<n>" or of a marketing name; -1 if none
-    int m_count;
+    int Count() const;               // enumerates the devices on first use (hipGetDeviceCount: ~50 ms)
+    mutable int m_count = -1;
 };
 
 class HipSha256D::Instance : public ISha256D {
@@ -65,6 +73,15 @@ public:
     bool AddLines(const char* buf, size_t len, bool final, Tally* tally) override;
     bool Reset() override { return false; }   // reference IVkSha256DInstance::Reset, SHA-256vk.h:28
 
+    // Pre-packed input (bindings; bench.py's PCIe-inclusive measurement).  StagePacked copies `count` strings that are
+    // already in the packed layout into pinned batches, in stream order, with the same batch / slice hand-offs as Add() --
+    // but holds the batches back instead of mapping them.  RootOfStaged() then runs exactly what Add() and Root() would
+    // have run on them: every batch through Mappings::Map (H2D on the copy stream, map kernel behind it), slices to
+    // Reductions as they fill, the combine -- so that "pinned host memory -> root" can be timed on the product's own
+    // schedule.  The pools must be large enough to hold the staged batches and slices (cfg.max_inflight, cfg.slice_budget).
+    bool StagePacked(const uint32_t* data, const vkmr_metadata* meta, size_t count);
+    out_type RootOfStaged();
+
     bool Ok() const { return m_ok; }
     // "proof: ..." lines of the requested Merkle proof (cfg.proof_index), valid after Root().
     std::vector<std::string> ProofLines() const { return m_reductions ? m_reductions->ProofLines() : std::vector<std::string>(); }
@@ -72,11 +89,14 @@ public:
 private:
     struct PerDevice {
         int dev;
-        vkmr_stream map_stream = nullptr, reduce_stream = nullptr;
+        vkmr_stream map_stream = nullptr, copy_stream = nullptr, reduce_stream = nullptr;
         std::unique_ptr<Batches> batches;
         bool prefetched = false;   // the pipeline's batches have been requested from the helper thread
     };
     PerDevice& Dev(int dev);
+    void JoinSetup();                                    // the copy and reduce streams are created on a helper thread: wait for it
+    bool EnsureGeometry(const char* first_span, size_t len);   // slices and reductions exist from the first string on
+    uint32_t ChooseSliceLog2(const char* first_span, size_t len, std::string* why) const;
     bool MapCurrent();                                   // dispatches m_batch into the current slice's pending reservations
     void Account(std::vector<Slice>&& retired);          // retired sub-slices -> fill counts -> reductions
     bool StartSliceAndBatch();
@@ -86,14 +106,20 @@ private:
     bool GrowBatchesFor(int dev, size_t string_bytes);   // a string larger than the current batches: grow them, if allowed
 
     HipConfig m_cfg;
+    std::vector<int> m_device_ids;
+    bool m_geometry = false;
     std::vector<PerDevice> m_devs;
     Slices m_slices;
     Batch m_batch;
     std::unique_ptr<Mappings> m_mappings;
     std::unique_ptr<Reductions> m_reductions;
     std::unique_ptr<class ForkJoin> m_pool;   // packs large input spans in parallel
+    std::thread m_setup;                      // creates the streams the first batch does not need yet (hipStreamCreate: ~15 ms each)
+    bool m_setup_ok = true;
     bool m_ok;
     bool m_draining = false;   // Root() has begun: nothing more will be packed
+    struct Staged { Batch batch; Slice sub; int dev; };
+    std::vector<Staged> m_staged;
 };
 
 }  // namespace vkmr

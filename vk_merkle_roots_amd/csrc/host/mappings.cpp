@@ -1,6 +1,6 @@
 // mappings.cpp -- in-flight mappings (reference src/vkmr/Mappings.cpp:294-365, without
-// the descriptor/command-buffer machinery: one mapping = two async copies + one kernel
-// launch + events on the op's stream).
+// the descriptor/command-buffer machinery: one mapping = two async copies on the device's copy
+// stream, an event, one kernel launch on its map stream, and the events that time and retire it).
 #include <iostream>
 
 #include "ops.hpp"
@@ -11,7 +11,7 @@ namespace {
 struct Mapping {
     Batch batch;
     Slice sub;
-    vkmr_event begin = nullptr, done = nullptr;
+    vkmr_event begin = nullptr, copied = nullptr, done = nullptr;
     int dev = -1;
 };
 
@@ -24,32 +24,39 @@ public:
         for (auto& e : m_spare) vkmr_hip_event_destroy(e.first, e.second);
     }
 
-    HipResult Map(Batch&& batch, slice_type&& sub, vkmr_stream stream) override
+    HipResult Map(Batch&& batch, slice_type&& sub, vkmr_stream stream, vkmr_stream copy_stream) override
     {
         if (batch.Empty() || !sub) return VKMR_OK;   // nothing to do
         Mapping m;
         m.dev = sub.Device();
         m.begin = Event(m.dev);
+        m.copied = Event(m.dev);
         m.done = Event(m.dev);
-        if (!m.begin || !m.done) {
-            if (m.begin) m_spare.emplace_back(m.dev, m.begin);
-            if (m.done) m_spare.emplace_back(m.dev, m.done);
+        auto give_back = [&] {
+            for (vkmr_event e : {m.begin, m.copied, m.done})
+                if (e) m_spare.emplace_back(m.dev, e);   // keep the events for the next mapping
+        };
+        if (!m.begin || !m.copied || !m.done) {
+            give_back();
             return VKMR_ERR_HIP;
         }
-        HipResult r = vkmr_hip_event_record(m.dev, m.begin, stream);
+        HipResult r = vkmr_hip_event_record(m.dev, m.begin, copy_stream);
         if (r == VKMR_OK)
-            r = vkmr_hip_memcpy_h2d_async(m.dev, stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
+            r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
         if (r == VKMR_OK)
-            r = vkmr_hip_memcpy_h2d_async(m.dev, stream, batch.DeviceMeta(), batch.HostMeta(),
+            r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceMeta(), batch.HostMeta(),
                                           batch.Count() * sizeof(vkmr_metadata));
+        if (r == VKMR_OK && copy_stream != stream) {
+            r = vkmr_hip_event_record(m.dev, m.copied, copy_stream);
+            if (r == VKMR_OK) r = vkmr_hip_stream_wait_event(m.dev, stream, m.copied);
+        }
         if (r == VKMR_OK)
             r = vkmr_hip_map_async(m.dev, stream, batch.DeviceData(), batch.Words(), batch.DeviceMeta(),
                                    (uint32_t)batch.Count(), sub.Cells());
         if (r == VKMR_OK) r = vkmr_hip_event_record(m.dev, m.done, stream);
         if (r != VKMR_OK) {
             std::cerr << "Failed to dispatch a mapping: " << vkmr_hip_last_error() << std::endl;
-            m_spare.emplace_back(m.dev, m.begin);   // keep the events for the next mapping
-            m_spare.emplace_back(m.dev, m.done);
+            give_back();
             return r;
         }
         m.batch = std::move(batch);
@@ -94,6 +101,7 @@ private:
                 std::cerr << "Mapping for slice #" << it->sub.Number() << " failed: " << vkmr_hip_last_error() << std::endl;
                 m_failed = true;
                 m_spare.emplace_back(it->dev, it->begin);
+                m_spare.emplace_back(it->dev, it->copied);
                 m_spare.emplace_back(it->dev, it->done);
                 it = m_inflight.erase(it);
                 continue;
@@ -105,6 +113,7 @@ private:
                           << it->batch.Size() << " byte(s)) finished in " << ms << "ms." << std::endl;
             }
             m_spare.emplace_back(it->dev, it->begin);
+            m_spare.emplace_back(it->dev, it->copied);
             m_spare.emplace_back(it->dev, it->done);
             out.push_back(std::move(it->sub));
             it = m_inflight.erase(it);   // the batch goes back to its pool here

@@ -23,9 +23,12 @@ public:
     typedef Slice slice_type;
     virtual ~Mappings() = default;
 
-    // Uploads the batch and hashes it into the sub-slice, asynchronously.  The batch
-    // and the sub-slice view are held until the mapping retires.
-    virtual HipResult Map(Batch&&, slice_type&&, vkmr_stream) = 0;
+    // Uploads the batch (on `copy_stream`: its two H2D copies run beside the previous batch's map kernel) and hashes
+    // it into the sub-slice (on `map_stream`, after an event says the copies have landed), asynchronously.  The batch
+    // -- pinned buffers and its own HBM landing zone -- and the sub-slice view are held until the mapping retires.
+    // The two streams take the place of the reference's round-robin compute queues (src/vkmr/Devices.cpp:525-538) and
+    // of its one submit per batch (src/vkmr/Mappings.cpp:135-232).  copy_stream may equal map_stream.
+    virtual HipResult Map(Batch&&, slice_type&&, vkmr_stream map_stream, vkmr_stream copy_stream) = 0;
     // Polls in-flight mappings; returns the sub-slices of those that finished.
     virtual std::vector<slice_type> Update() = 0;
     // Blocks until every in-flight mapping has finished; returns their sub-slices.

@@ -264,6 +264,16 @@ private:
         size_t di = 0;
         while (di < m_devs.size() && m_devs[di].dev != slice.Device()) ++di;
         if (di == m_devs.size() || slice.Number() == 0) return VKMR_ERR_INVALID;
+        // The combine reads the roots as dealt: slice k on device (k - 1) % D, entry (k - 1) / D of that device's array
+        // (WaitFor, roots_in_slice_order).  A slice that sits anywhere else -- an allocator that fell back to another
+        // device, a different device order -- would put two roots into one cell or the cells into the wrong order, and
+        // only the COUNT of roots is checked later: refuse it here and mark the run failed.
+        if (di != (size_t)((slice.Number() - 1) % m_devs.size())) {
+            std::cerr << "Slice #" << slice.Number() << " lives on device index " << di << ", the deal puts it on "
+                      << (slice.Number() - 1) % m_devs.size() << ": its root would land in the wrong place." << std::endl;
+            m_failed = true;
+            return VKMR_ERR_INVALID;
+        }
         PerDevice& d = m_devs[di];
         d.stream = stream;
         Reduction r;

@@ -273,10 +273,12 @@ static uint32_t g_last_map_tile = 0;
 //   average packed string < 128 B                    LDS-staged tiles (HBM traffic == algorithmic bytes)
 //   >= 1 KiB on average, full-size launch            whole 128-byte lines through a per-lane LDS window
 //   in between, or a launch too short for 512 lanes  per-lane 16-byte loads
-#define VKMR_MAP_STAGED_KERNEL map_kernel<512, 1024, 17664, 0, false>
-#define VKMR_MAP_LINEWIN_KERNEL map_kernel<512, 2048, 512 * VKMR_MAP_WIN_STRIDE, 4, true>
-#define VKMR_MAP_DIRECT512_KERNEL map_kernel<512, 2048, 64, 2, true>
-#define VKMR_MAP_DIRECT256_KERNEL map_kernel<256, 2048, 64, 2, true>
+static_assert(512 * VKMR_MAP_WIN_STRIDE == 34816, "the line-window kernel is named by its staging words below");
+// (spelled with every template argument: the names must read exactly as a profiler prints them, provenance.py)
+#define VKMR_MAP_STAGED_KERNEL map_kernel<512, 1024, 17664, 0, false, 0>
+#define VKMR_MAP_LINEWIN_KERNEL map_kernel<512, 2048, 34816, 4, true, 0>
+#define VKMR_MAP_DIRECT512_KERNEL map_kernel<512, 2048, 64, 2, true, 0>
+#define VKMR_MAP_DIRECT256_KERNEL map_kernel<256, 2048, 64, 2, true, 0>
 
 // Strings per LDS-staged tile: what is expected to fit the staging area, three standard deviations of a tile's
 // size below it (string lengths spread like rndm's, uniform in [1, max]: sigma / mean of T strings is about
@@ -371,7 +373,10 @@ const char* vkmr_hip_kernel_info(void)
         case MAP_EXPERIMENT: map = "map=EXPERIMENT (VKMR_MAP_VARIANT; not a product build)"; break;
         default: break;
     }
-    snprintf(buf, sizeof buf, "%s tile=%u reduce=reduce_pass_kernel(m<=%d)+reduce_collapse_kernel+reduce_tail_kernel(<=%d nodes)", map,
+#ifndef VKMR_BUILD_ID
+#define VKMR_BUILD_ID "unknown"
+#endif
+    snprintf(buf, sizeof buf, "%s tile=%u reduce=reduce_pass_kernel(m<=%d)+reduce_collapse_kernel+reduce_tail_kernel(<=%d nodes) build=" VKMR_BUILD_ID, map,
              g_last_map_tile, VKMR_PASS_MAXM, VKMR_TAIL_MAX);
     return buf;
 }

@@ -163,6 +163,41 @@ def transform(lines, gap=0, level=1, split_every=0):
     return out, stats
 
 
+def hash_blocks(lines):
+    """Static VALU counts of the SHA-256 basic blocks of every kernel in a (transformed) assembly listing: a basic block
+    with more than 100 rotates is one unrolled hash -- the node hash of the reduce kernels (three compressions), the
+    per-64-byte-block compression and the digest hash of the map kernels.  {kernel: [{valu, complex, simple, rotates}]}
+    in program order.  bench.py prices the kernels with these (issue turns = max(valu / 2, complex))."""
+    out, cur, bb = {}, None, None
+
+    def close():
+        if cur is not None and bb and bb["rotates"] > 100:
+            out[cur].append(bb)
+    for ln in lines:
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            close()
+            cur, bb = m.group(1), {"valu": 0, "complex": 0, "simple": 0, "rotates": 0}
+            out[cur] = []
+            continue
+        if cur is None:
+            continue
+        if re.match(r"^\.LBB\w+:", ln):
+            close()
+            bb = {"valu": 0, "complex": 0, "simple": 0, "rotates": 0}
+            continue
+        k = classify(ln)
+        if k in ("C", "S"):
+            bb["valu"] += 1
+            bb["complex" if k == "C" else "simple"] += 1
+            if "v_alignbit_b32" in ln:
+                bb["rotates"] += 1
+        if ln.strip().startswith("s_endpgm"):
+            close()
+            cur, bb = None, None
+    return {k: v for k, v in out.items() if v}
+
+
 def main(argv):
     gap = 0
     args = [a for a in argv if not a.startswith("--")]
