@@ -468,6 +468,34 @@ def set3():
         add_pattern(f"rounds16w_t{threads}", full, f"16 rounds with schedule in hipcc's order, {threads}-lane workgroups (reference point)", live_out=wst("x"), threads=threads)
 
 
+def set4():
+    """Fourth pass: does priority help a LONE wavefront (the latency-bound top of the reduction runs one per SIMD)?  The same
+    16 rounds with the priority toggled around the complex runs, raised once and for all, or left alone."""
+    wst = lambda q: [f"{q}s{i}" for i in range(8)] + [f"{q}w{i}" for i in range(16)] + [f"{q}k"]   # noqa: E731
+    prog = ssa_temps(sha_rounds("x", 16, True), set(wst("x")))
+    alloc, lines, top = lower(prog, live_out=wst("x"))
+    tl = [(ln, "H" if ins.op in HALF else "F") for (ins, _, _), ln in zip(alloc, lines)]
+    instrs, slots = len(prog), sum(i.slots() for i in prog)
+
+    def toggled(hi_kind, level=1):
+        out, cur = [], None
+        for ln, kind in tl:
+            if kind != cur:
+                out.append(f"s_setprio {level}" if kind == hi_kind else "s_setprio 0")
+                cur = kind
+            out.append(ln)
+        return out + ["s_setprio 0"]
+    plain = [ln for ln, _ in tl]
+    add_raw("r16_plain", [plain], instrs, slots, top, "16 rounds with schedule, hipcc order, priority untouched")
+    add_raw("r16_prioH", [toggled("H")], instrs, slots, top, "s_setprio 1 around every complex run")
+    add_raw("r16_prioH3", [toggled("H", 3)], instrs, slots, top, "s_setprio 3 around every complex run")
+    add_raw("r16_const1", [["s_setprio 1"] + plain], instrs, slots, top, "s_setprio 1 once per loop body, never lowered")
+    add_raw("r16_const3", [["s_setprio 3"] + plain], instrs, slots, top, "s_setprio 3 once per loop body, never lowered")
+    add_raw("r16_nops", [[x if not x.startswith("s_setprio") else "s_nop 0" for x in toggled("H")]], instrs, slots, top, "an s_nop 0 wherever prioH has an s_setprio (same scalar instruction count, no priority change)")
+    add_pattern("H_align", mix("H" * 64), "pure v_alignbit_b32")
+    add_pattern("F_xor", mix("F" * 64), "pure v_xor_b32")
+
+
 def write(out):
     with open(out, "w") as f:
         f.write("// generated by tools/gen_issue_patterns.py -- do not edit\n")
@@ -514,7 +542,7 @@ def write(out):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "set2"
-    {"set1": set1, "set2": set2, "set3": set3}[which]()
+    {"set1": set1, "set2": set2, "set3": set3, "set4": set4}[which]()
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "issue_patterns.inc")
     write(out)
     print(f"{which}: {len(PATTERNS)} patterns -> {out}")

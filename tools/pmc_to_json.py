@@ -74,6 +74,7 @@ def main():
             for r in csv.DictReader(open(path)):
                 if "map_kernel" in r["Kernel_Name"]:
                     ls[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    res["long_strings_map_kernel_symbol"] = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         if ls.get("FETCH_SIZE") and ls.get("WRITE_SIZE"):
             rd = sum(ls["FETCH_SIZE"]) / len(ls["FETCH_SIZE"]) * 1024 * 2
             wr = sum(ls["WRITE_SIZE"]) / len(ls["WRITE_SIZE"]) * 1024

@@ -28,6 +28,7 @@ STAMPS_LIB = os.path.join(PKG, "libvkmr_hip_stamps.so")
 EXP_LIB = os.path.join(ROOT, "build", "ab", "libexp.so")
 ARCH = "gfx950"
 SPLIT_ADD3_EVERY = 4   # isa_prio_pass: every 4th v_add3_u32 becomes two v_add_u32 (balances the two issue slots: -1.4 %, profiles/r03_ab_add3_split.txt)
+LATENCY_BOUND_KERNELS = ("reduce_collapse_kernel",)   # one wavefront per SIMD: left as hipcc emits it (113 vs 140 us; the tail, 16 wavefronts on one CU, gains from the pass: 137 vs 220 us -- profiles/r03_reduce_top_kernels.txt)
 PRIO_GAP = 0    # isa_prio_pass: complex-instruction runs separated by at most this many simple instructions are merged
 
 
@@ -86,7 +87,7 @@ def source_id(defines=(), prio_gap=PRIO_GAP, split_every=SPLIT_ADD3_EVERY):
         feed(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             feed(fh.read())
-    feed(repr((sorted(defines), prio_gap, split_every, ARCH)).encode())
+    feed(repr((sorted(defines), prio_gap, split_every, LATENCY_BOUND_KERNELS, ARCH)).encode())
     return f"{crc & 0xffffffff:08x}{adl & 0xffffffff:08x}"
 
 
@@ -112,7 +113,7 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     from . import isa_prio_pass
     with open(dev_s) as f:
         lines = f.readlines()
-    out, stats = isa_prio_pass.transform(lines, prio_gap, prio_level, split_every)
+    out, stats = isa_prio_pass.transform(lines, prio_gap, prio_level, split_every, LATENCY_BOUND_KERNELS)
     with open(prio_s, "w") as f:
         f.writelines(out)
     _run([_llvm("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", prio_s, "-o", dev_o])

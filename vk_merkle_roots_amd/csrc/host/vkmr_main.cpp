@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -51,8 +52,18 @@ static int run(vkmr::ISha256D& backend)
     return 0;
 }
 
+// VKMR_TIMING=1: milliseconds since main() began at the points where a short run spends its time outside the stopwatch
+// (device enumeration, backend construction, exit), on stderr.
+static void stamp(const char* what)
+{
+    static const bool on = getenv("VKMR_TIMING") != nullptr;
+    static const auto t0 = std::chrono::steady_clock::now();
+    if (on) std::cerr << "[timing] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() << " ms" << std::endl;
+}
+
 int main(int argc, const char* argv[])
 {
+    stamp("main");
     vkmr::CpuSha256D cpu;
     vkmr::HipSha256D gpus;
     std::string choice;
@@ -73,6 +84,7 @@ int main(int argc, const char* argv[])
     std::cout << "Initializing for: " << choice << std::endl;
     if (cpu.Name() == choice) return run(cpu);   // before any question to the GPU runtime: `vkmr CPU` makes no HIP call
     if (gpus.Has(choice)) {
+        stamp("devices enumerated");
         vkmr::HipConfig cfg = vkmr::HipConfig::FromEnv();
         struct stat st;
         if (fstat(STDIN_FILENO, &st) == 0 && S_ISREG(st.st_mode)) {   // `vkmr hip:all < file`: the size of the input is known
@@ -80,12 +92,17 @@ int main(int argc, const char* argv[])
             if (st.st_size > (at > 0 ? at : 0)) cfg.expected_input_bytes = (uint64_t)(st.st_size - (at > 0 ? at : 0));
         }
         auto instance = gpus.Get(choice, cfg);
+        stamp("backend constructed");
         const int rc = run(*instance);
+        stamp("root printed");
 #if !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__) && !defined(VKMR_ORDERLY_EXIT)
         // The root is printed: what is left is giving pinned buffers, HBM, streams and events back one call at a time
         // (hipHostFree alone: 40 ms of a 150 ms run) just before the process ends and the driver reclaims all of it
         // at once.  Skip the destructors; VKMR_ORDERLY_EXIT=1 (or a sanitizer build) keeps them.
-        if (!getenv("VKMR_ORDERLY_EXIT")) {
+        // (a profiler writes its output from exit handlers: under rocprofv3 -- it preloads its tool library -- or with
+        // VKMR_ORDERLY_EXIT set, leave the ordinary way)
+        const char* preload = getenv("LD_PRELOAD");
+        if (!getenv("VKMR_ORDERLY_EXIT") && !getenv("ROCP_TOOL_LIBRARIES") && !(preload && preload[0])) {
             std::cout.flush();
             std::cerr.flush();
             fflush(nullptr);

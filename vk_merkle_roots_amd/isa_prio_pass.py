@@ -64,7 +64,14 @@ def classify(line):
 _ADD3 = re.compile(r"^(\s+)v_add3_u32\s+(v\d+),\s*([^,]+),\s*([^,]+),\s*([^,\s]+)\s*$")
 
 
-def split_add3(lines, every):
+def _kernel_of(line):
+    """The (mangled) name when `line` is a function label, else None."""
+    if _LABEL.match(line) and not line.startswith(".L"):
+        return line.split(":")[0]
+    return None
+
+
+def split_add3(lines, every, skip=()):
     """Balance the two issue slots: v_add3_u32 is a complex instruction, two v_add_u32 are simple ones.  The node hash has
     2 108 complex and 1 500 simple instructions, i.e. the complex slot is the longer queue; every add3 that is split moves
     one instruction from it to the other.  `every` = k splits every k-th v_add3_u32 of each kernel (0 = none).
@@ -73,9 +80,15 @@ def split_add3(lines, every):
         return lines, 0
     out, n, done = [], 0, 0
     isv = lambda x: re.fullmatch(r"v\d+", x) is not None   # noqa: E731
+    skipping = False
     for ln in lines:
-        if _LABEL.match(ln) and not ln.startswith(".L"):
+        k = _kernel_of(ln)
+        if k is not None:
             n = 0
+            skipping = any(pat in k for pat in skip)
+        if skipping:
+            out.append(ln)
+            continue
         m = _ADD3.match(ln.split(";")[0].rstrip() if ";" in ln else ln.rstrip("\n"))
         if not m:
             out.append(ln)
@@ -110,10 +123,14 @@ def split_add3(lines, every):
     return out, done
 
 
-def transform(lines, gap=0, level=1, split_every=0):
-    lines, nsplit = split_add3(lines, split_every)
+def transform(lines, gap=0, level=1, split_every=0, skip=()):
+    """skip: kernels (substrings of their names) left exactly as hipcc emitted them -- the latency-bound ones, launched
+    with one wavefront per SIMD: a lone wavefront has nobody to pair with, and every s_setprio (and the second
+    instruction of a split add3) is one more issue turn on its critical path."""
+    lines, nsplit = split_add3(lines, split_every, skip)
     out, stats = [], {"runs": 0, "complex": 0, "simple_inside": 0, "kernels": 0, "add3_split": nsplit}
     in_text = False
+    skipping = False
     base_prio = 0
     i, n = 0, len(lines)
     while i < n:
@@ -127,6 +144,11 @@ def transform(lines, gap=0, level=1, split_every=0):
         if kind == "L" and not ln.startswith(".L"):   # a function symbol: every kernel starts at priority 0
             base_prio = 0
             stats["kernels"] += 1
+            skipping = any(pat in ln for pat in skip)
+        if in_text and skipping:
+            out.append(ln)
+            i += 1
+            continue
         if kind == "P":
             m = re.search(r"s_setprio\s+(\d+)", ln)
             base_prio = int(m.group(1)) if m else 0
