@@ -496,6 +496,55 @@ def set4():
     add_pattern("F_xor", mix("F" * 64), "pure v_xor_b32")
 
 
+def set5():
+    """Fifth pass: WHICH complex instructions need the raised priority?  The 16 rounds with s_setprio around the rotates only,
+    around the three-operand adds only, with two levels, and with the simple run lowered below a base priority instead."""
+    wst = lambda q: [f"{q}s{i}" for i in range(8)] + [f"{q}w{i}" for i in range(16)] + [f"{q}k"]   # noqa: E731
+    prog = ssa_temps(sha_rounds("x", 16, True), set(wst("x")))
+    alloc, lines, top = lower(prog, live_out=wst("x"))
+    kinds = [("R" if ins.op == "v_alignbit_b32" else ("A" if ins.op == "v_add3_u32" else "F")) for (ins, _, _) in alloc]
+    instrs, slots = len(prog), sum(i.slots() for i in prog)
+
+    def toggled(level_of):
+        """level_of: kind -> priority while such instructions run."""
+        out, cur = [], 0
+        for ln, k in zip(lines, kinds):
+            want = level_of[k]
+            if want != cur:
+                out.append(f"s_setprio {want}")
+                cur = want
+            out.append(ln)
+        return out + ["s_setprio 0"]
+    add_raw("p_plain", [lines], instrs, slots, top, "16 rounds, priority untouched")
+    add_raw("p_all_complex", [toggled({"R": 1, "A": 1, "F": 0})], instrs, slots, top, "priority 1 for rotates and add3 (what the pass does)")
+    add_raw("p_rot_only", [toggled({"R": 1, "A": 0, "F": 0})], instrs, slots, top, "priority 1 for rotates only")
+    add_raw("p_add3_only", [toggled({"R": 0, "A": 1, "F": 0})], instrs, slots, top, "priority 1 for add3 only")
+    add_raw("p_two_levels", [toggled({"R": 2, "A": 1, "F": 0})], instrs, slots, top, "priority 2 for rotates, 1 for add3")
+    add_raw("p_two_levels_b", [toggled({"R": 1, "A": 2, "F": 0})], instrs, slots, top, "priority 1 for rotates, 2 for add3")
+    add_raw("p_base1", [toggled({"R": 3, "A": 3, "F": 1})], instrs, slots, top, "priority 3 for complex, 1 for simple")
+    # the same with every 3rd add3 split (the balance of the two slots)
+    import copy
+    sp, n = [], 0
+    for ins in prog:
+        if ins.op == "v_add3_u32":
+            n += 1
+            if n % 3 == 0 and ins.dst not in ins.srcs[1:]:
+                sp.append(I("v_add_u32", ins.dst, [ins.srcs[0], ins.srcs[1]]))
+                sp.append(I("v_add_u32", ins.dst, [ins.dst, ins.srcs[2]]))
+                continue
+        sp.append(copy.copy(ins))
+    alloc2, lines2, top2 = lower(sp, live_out=wst("x"))
+    k2 = [("C" if ins.op in HALF else "F") for (ins, _, _) in alloc2]
+    out, cur = [], 0
+    for ln, k in zip(lines2, k2):
+        want = 1 if k == "C" else 0
+        if want != cur:
+            out.append(f"s_setprio {want}")
+            cur = want
+        out.append(ln)
+    add_raw("p_split3", [out + ["s_setprio 0"]], len(sp), slots, top2, f"every 3rd add3 split ({len(sp)} instr), priority 1 for complex")
+
+
 def write(out):
     with open(out, "w") as f:
         f.write("// generated by tools/gen_issue_patterns.py -- do not edit\n")
@@ -542,7 +591,7 @@ def write(out):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "set2"
-    {"set1": set1, "set2": set2, "set3": set3, "set4": set4}[which]()
+    {"set1": set1, "set2": set2, "set3": set3, "set4": set4, "set5": set5}[which]()
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "issue_patterns.inc")
     write(out)
     print(f"{which}: {len(PATTERNS)} patterns -> {out}")

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
 E=$GRAFT_REPO_ROOT/build/ab
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py -m gpu -x -q -k "reduce or proof or slices or random" > gpurun_out/r03/pytest_collapse.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r03/pytest_collapse.log
 for lib in default $E/libprev.so; do
   if [ "$lib" = default ]; then unset VKMR_HIP_LIB; else export VKMR_HIP_LIB=$lib; fi
   for r in 1 2; do python3 tools/reduce_probe.py 26 20; done
@@ -8,5 +9,5 @@ for lib in default $E/libprev.so; do
 import csv, glob
 for f in glob.glob('/tmp/redprof/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)): print(r['Name'][:28], r['Calls'], 'avg us', float(r['AverageNs'])/1e3, 'min', float(r['MinNs'])/1e3, 'max', float(r['MaxNs'])/1e3)" )
-done > gpurun_out/r03/reduce_probe.txt 2>&1
-cat gpurun_out/r03/reduce_probe.txt
+done > gpurun_out/r03/reduce_probe2.txt 2>&1
+cat gpurun_out/r03/reduce_probe2.txt

@@ -29,6 +29,7 @@ EXP_LIB = os.path.join(ROOT, "build", "ab", "libexp.so")
 ARCH = "gfx950"
 SPLIT_ADD3_EVERY = 4   # isa_prio_pass: every 4th v_add3_u32 becomes two v_add_u32 (balances the two issue slots: -1.4 %, profiles/r03_ab_add3_split.txt)
 LATENCY_BOUND_KERNELS = ("reduce_collapse_kernel",)   # one wavefront per SIMD: left as hipcc emits it (113 vs 140 us; the tail, 16 wavefronts on one CU, gains from the pass: 137 vs 220 us -- profiles/r03_reduce_top_kernels.txt)
+ROTATE_LEVEL = None    # isa_prio_pass: priority of v_alignbit_b32 when it differs from the other complex instructions' (1)
 PRIO_GAP = 0    # isa_prio_pass: complex-instruction runs separated by at most this many simple instructions are merged
 
 
@@ -91,7 +92,7 @@ def source_id(defines=(), prio_gap=PRIO_GAP, split_every=SPLIT_ADD3_EVERY):
     return f"{crc & 0xffffffff:08x}{adl & 0xffffffff:08x}"
 
 
-def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, split_every=SPLIT_ADD3_EVERY):
+def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, split_every=SPLIT_ADD3_EVERY, rotate_level=ROTATE_LEVEL):
     """hipcc in five explicit steps so that the issue-priority pass (isa_prio_pass.py) can run on the device assembly:
     device code -> .s, pass, assemble + link the code object, bundle it, compile the host side around that bundle.
     prio_gap None = plain one-step hipcc build (no pass), for A/B timing."""
@@ -113,7 +114,7 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     from . import isa_prio_pass
     with open(dev_s) as f:
         lines = f.readlines()
-    out, stats = isa_prio_pass.transform(lines, prio_gap, prio_level, split_every, LATENCY_BOUND_KERNELS)
+    out, stats = isa_prio_pass.transform(lines, prio_gap, prio_level, split_every, LATENCY_BOUND_KERNELS, rotate_level)
     with open(prio_s, "w") as f:
         f.writelines(out)
     _run([_llvm("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", prio_s, "-o", dev_o])

@@ -209,14 +209,15 @@ __global__ __launch_bounds__(VKMR_TAIL_MAX / 2) void reduce_tail_kernel(const No
 // steps as in the reference's subgroup shader.  Lane utilisation is poor by
 // construction here but these passes are latency-bound: what counts
 // is the ~9 us one wavefront needs per level, not the idle lanes.
-__global__ __launch_bounds__(64) void reduce_collapse_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
-                                                             Node* __restrict__ out0)
+__global__ __launch_bounds__(VKMR_COLLAPSE_WAVES * 64) void reduce_collapse_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                                                     Node* __restrict__ out0)
 {
     const uint64_t n_in = slice_count(geom);
     const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
     Node* __restrict__ out = out0 + blockIdx.y * geom.out_stride;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t j = (uint64_t)blockIdx.x * 64u + lane;   // level-1 node of this lane
+    const uint32_t lane = threadIdx.x & 63u;
+    // each wavefront of the workgroup collapses its own 128 nodes
+    const uint64_t j = ((uint64_t)blockIdx.x * VKMR_COLLAPSE_WAVES + (threadIdx.x >> 6)) * 64u + lane;   // level-1 node of this lane
     uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (2 * j < n_in) {
         const Node a = vkmr_dev::load_node(in + 2 * j);

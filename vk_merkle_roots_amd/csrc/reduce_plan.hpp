@@ -16,6 +16,9 @@
                             // 3 levels = 6 wavefronts per SIMD, 4 = 5; with the issue-priority pass occupancy pays (4.60 vs 4.80 ms per 2^26, profiles/r03_ab_occupancy.txt)
 #endif
 
+#ifndef VKMR_COLLAPSE_WAVES
+#define VKMR_COLLAPSE_WAVES 1   // wavefronts per workgroup of reduce_collapse_kernel (4, "one per SIMD of a CU": 121 vs 111 us, profiles/r03_reduce_top_kernels.txt)
+#endif
 #ifndef VKMR_TAIL_MAX
 #define VKMR_TAIL_MAX 2048  // reduce_tail_kernel takes up to this many nodes: 1024 lanes = 16 wavefronts of one workgroup
 #endif

@@ -441,8 +441,9 @@ static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32
             if (grid > 0x7fffffffull) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: slice too large");
             hipLaunchKernelGGL(reduce_pass_kernel, dim3((uint32_t)grid, nslices), dim3(VKMR_PASS_WAVES * 64), 0, stream, in, g, out, m);
         } else {
-            hipLaunchKernelGGL(reduce_collapse_kernel, dim3((uint32_t)ceil_shift(n, 7), nslices), dim3(64), 0, stream, in, g,
-                               st.levels, out);
+            const uint64_t cwaves = ceil_shift(n, 7);
+            hipLaunchKernelGGL(reduce_collapse_kernel, dim3((uint32_t)((cwaves + VKMR_COLLAPSE_WAVES - 1) / VKMR_COLLAPSE_WAVES), nslices),
+                               dim3(VKMR_COLLAPSE_WAVES * 64), 0, stream, in, g, st.levels, out);
         }
         VKMR_TRY(hipGetLastError());
         in = out;

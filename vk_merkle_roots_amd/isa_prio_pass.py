@@ -123,7 +123,7 @@ def split_add3(lines, every, skip=()):
     return out, done
 
 
-def transform(lines, gap=0, level=1, split_every=0, skip=()):
+def transform(lines, gap=0, level=1, split_every=0, skip=(), rotate_level=None):
     """skip: kernels (substrings of their names) left exactly as hipcc emitted them -- the latency-bound ones, launched
     with one wavefront per SIMD: a lone wavefront has nobody to pair with, and every s_setprio (and the second
     instruction of a split add3) is one more issue turn on its critical path."""
@@ -178,8 +178,18 @@ def transform(lines, gap=0, level=1, split_every=0, skip=()):
         stats["runs"] += 1
         stats["complex"] += sum(1 for x in run if classify(x) == "C")
         stats["simple_inside"] += sum(1 for x in run if classify(x) == "S")
-        out.append(f"\ts_setprio {level}\n")
-        out.extend(run)
+        if rotate_level is None or rotate_level == level:
+            out.append(f"\ts_setprio {level}\n")
+            out.extend(run)
+        else:   # two levels: rotates above the other complex instructions (profiles/r03_issue_patterns_set5.txt)
+            cur = None
+            for x in run:
+                if classify(x) == "C":
+                    want = rotate_level if "v_alignbit_b32" in x else level
+                    if want != cur:
+                        out.append(f"\ts_setprio {want}\n")
+                        cur = want
+                out.append(x)
         out.append("\ts_setprio 0\n")
         i = last_c + 1
     return out, stats
