@@ -2,7 +2,7 @@
 # tools/ab_env.sh -- interleaved A/B under bench.py in one gpurun call (GPU box).  Each argument is "label:VAR=value,VAR=value"
 # (VKMR_HIP_LIB, VKMR_MAP_VARIANT ...); "default:" is the product library with no knob.
 cd ${GRAFT_REPO_ROOT:-.}
-BENCH_ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline --no-pipeline --no-long-strings}
+BENCH_ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline --no-pipeline --no-long-strings --no-clock-leg}
 for round in 1 2; do for spec in "$@"; do
   label=${spec%%:*}; envs=${spec#*:}
   ( OLDIFS=$IFS; IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; IFS=$OLDIFS

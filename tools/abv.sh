@@ -1,9 +1,11 @@
 #!/bin/bash
 # interleaved timing of VKMR_MAP_VARIANT values in one gpurun call.  Usage: bash tools/abv.sh "<bench args>" 0 5 6 ...
 ARGS=$1; shift
+# the knobs exist in the experiments build only (vk_merkle_roots_amd/build.py: build_experiments -> build/ab/libexp.so)
+export VKMR_HIP_LIB=${VKMR_HIP_LIB:-${GRAFT_REPO_ROOT:-$(pwd)}/build/ab/libexp.so}
 for round in 1 2; do
   for v in "$@"; do
-    VKMR_MAP_VARIANT=$v timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline 2>/dev/null | python3 -c "
+    VKMR_MAP_VARIANT=$v timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --no-clock-leg 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readlines()[-1])
 w = d['valu_roofline']

@@ -1,10 +1,11 @@
 #!/bin/bash
 # FETCH_SIZE / time of the long-string map launch (rndm 42 2^21 4096, one batch), per fetch mode (GPU box).
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+export VKMR_HIP_LIB=${VKMR_HIP_LIB:-$REPO/build/ab/libexp.so}   # the knobs exist in the experiments build only
 cd /tmp && export TMPDIR=/tmp
 for v in 0 3; do
   rm -rf /tmp/fc_$v
-  VKMR_MAP_VARIANT=$v timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/fc_$v -- python3 $REPO/bench.py --leaves-log2 21 --maxlen 4096 --batch-log2 21 --slice-log2 21 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /tmp/fc_$v.log 2>&1
+  VKMR_MAP_VARIANT=$v timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/fc_$v -- python3 $REPO/bench.py --leaves-log2 21 --maxlen 4096 --batch-log2 21 --slice-log2 21 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-leg --no-pipeline > /tmp/fc_$v.log 2>&1
   python3 - $v <<'PY'
 import csv, glob, sys
 t = sys.argv[1]
