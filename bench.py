@@ -261,7 +261,7 @@ def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=10):
                                                 "long_strings_map_hbm_bytes_per_launch", long_strings_workload=f"rndm {seed} 2^{count_log2} {maxlen}, one batch")
     return {"workload": f"rndm {seed} 2^{count_log2} {maxlen}, one batch", "strings": n, "input_bytes": int(b.words * 4), "map_ms": ms,
             "map_mode": info.split(" reduce=")[0],
-            "leaf_hashes_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "kernel": "map_kernel (line-window mode)", "achieved": nbytes / (ms * 1e-3) / 1e9,
+            "leaf_hashes_per_s": n / (ms * 1e-3), "roofline": {"bound": "hbm", "kernel": "map_kernel (" + (provenance.map_symbol_of(info) or "?") + ")", "achieved": nbytes / (ms * 1e-3) / 1e9,
                                                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                                "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": int(nbytes)},
             "blocks": blocks, "compressions_per_string": blocks / n + 1}

@@ -58,8 +58,7 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
         case 13: launch_staged(map_kernel<1024, 2048, 34816, 0>, 1024, 2048, 34816); break;  // one 1024-lane workgroup per CU, 136 KiB tiles of 2048 strings
         default:
             // the shipped choice, under the FIT / TILE / DYNLDS knobs
-            if (avg_words >= 256 && tile >= 1024u) launch_window();
-            else if (avg_words >= 32) launch_direct(true);
+            if (avg_words >= 32) launch_direct(true);
             else launch_staged(map_kernel<512, 1024, 17664, 0>, 512, 1024, 17664);
             break;
     }

@@ -38,8 +38,10 @@ using vkmr_dev::Node;
 //           times and re-fetched once it has left L2 (1.6x the algorithmic bytes at L2/fabric).
 //   MODE 1  per-wavefront gather: 16 lanes read one string's 64 contiguous bytes, four
 //           strings per load, transposed through LDS rows.  Kept as the measured alternative.
-// The kernel is bound by VALU issue, not by bytes: the three modes are within 5 % of
-// each other.
+//   MODE 4  (experiments build) whole 128-byte lines through a two-line LDS window per lane: 1.06x the algorithmic HBM
+//           reads for long strings, but 272 bytes of LDS per lane = two wavefronts per SIMD, which the instruction
+//           pairing of the issue pass (isa_prio_pass.py) punishes: 2.56 vs 2.26 ms on rndm * 4096.
+// The kernel is bound by VALU issue, not by bytes.
 // Digest i lands in out[i] whatever the processing order.
 
 #define VKMR_MAP_STAGE_PAD 32

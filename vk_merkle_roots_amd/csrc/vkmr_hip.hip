@@ -265,18 +265,20 @@ vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end,
 // ---- map ------------------------------------------------------------------------
 
 // What the last vkmr_hip_map_async of this process chose (reported by vkmr_hip_kernel_info).
-enum { MAP_NONE = 0, MAP_STAGED, MAP_DIRECT512, MAP_DIRECT256, MAP_LINEWIN, MAP_EXPERIMENT };
+enum { MAP_NONE = 0, MAP_STAGED, MAP_DIRECT512, MAP_DIRECT256, MAP_EXPERIMENT };
 static int g_last_map_mode = MAP_NONE;
 static uint32_t g_last_map_tile = 0;
 
 // The shipped fetch modes (csrc/map_kernel.hpp).  The mode is chosen from the batch alone:
-//   average packed string < 128 B                    LDS-staged tiles (HBM traffic == algorithmic bytes)
-//   >= 1 KiB on average, full-size launch            whole 128-byte lines through a per-lane LDS window
-//   in between, or a launch too short for 512 lanes  per-lane 16-byte loads
-static_assert(512 * VKMR_MAP_WIN_STRIDE == 34816, "the line-window kernel is named by its staging words below");
+//   average packed string < 128 B   LDS-staged tiles (HBM traffic == algorithmic bytes)
+//   longer                          per-lane 16-byte loads, 8 wavefronts per SIMD (256-lane workgroups when the launch is short)
+// Round 2 also shipped a third mode for strings of 1 KiB and more -- whole 128-byte lines through a per-lane LDS window,
+// 1.06x instead of 1.46x the algorithmic reads for 1-2 % of time.  Its 272 bytes of LDS per lane allow two wavefronts
+// per SIMD, and since the issue pass (isa_prio_pass.py) the instruction pairing that decides the speed needs
+// occupancy: 2.56 ms against 2.26 ms for the per-lane loads on rndm * 4096 (profiles/r03_long_strings_modes.txt).
+// It stays in the experiments build (VKMR_MAP_VARIANT=5).
 // (spelled with every template argument: the names must read exactly as a profiler prints them, provenance.py)
 #define VKMR_MAP_STAGED_KERNEL map_kernel<512, 1024, 17664, 0, false, 0>
-#define VKMR_MAP_LINEWIN_KERNEL map_kernel<512, 2048, 34816, 4, true, 0>
 #define VKMR_MAP_DIRECT512_KERNEL map_kernel<512, 2048, 64, 2, true, 0>
 #define VKMR_MAP_DIRECT256_KERNEL map_kernel<256, 2048, 64, 2, true, 0>
 
@@ -332,14 +334,8 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     }
 #endif
     uint32_t tile = direct_tile(count);
-    if (avg_words >= 256 && tile >= 1024u) {
-        // very long strings (>= 1 KiB on average), full-size launch: 1.06x instead of 1.46x the algorithmic HBM
-        // reads for 1-2 % of time (2.82 vs 2.77 ms on rndm * 4096, warm).  Below 1 KiB the window's per-string
-        // start-up shows (5 % at 600 B, 10 % at 200 B on average): profiles/r02_long_strings_line_window.txt
-        g_last_map_mode = MAP_LINEWIN;
-        hipLaunchKernelGGL((VKMR_MAP_LINEWIN_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
-    } else if (avg_words >= 32) {
-        // medium strings, or a short launch (smaller workgroups spread it over the chip)
+    if (avg_words >= 32) {
+        // strings of 128 B and more on average (a short launch: smaller workgroups spread it over the chip)
         if (tile >= 1024u) {
             g_last_map_mode = MAP_DIRECT512;
             hipLaunchKernelGGL((VKMR_MAP_DIRECT512_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
@@ -369,7 +365,6 @@ const char* vkmr_hip_kernel_info(void)
         case MAP_STAGED: map = "map=" VKMR_STR((VKMR_MAP_STAGED_KERNEL)) " LDS-staged tiles sorted by block count"; break;
         case MAP_DIRECT512: map = "map=" VKMR_STR((VKMR_MAP_DIRECT512_KERNEL)) " per-lane 16-byte loads"; break;
         case MAP_DIRECT256: map = "map=" VKMR_STR((VKMR_MAP_DIRECT256_KERNEL)) " per-lane 16-byte loads, short launch"; break;
-        case MAP_LINEWIN: map = "map=" VKMR_STR((VKMR_MAP_LINEWIN_KERNEL)) " 128-byte lines through a per-lane LDS window"; break;
         case MAP_EXPERIMENT: map = "map=EXPERIMENT (VKMR_MAP_VARIANT; not a product build)"; break;
         default: break;
     }
