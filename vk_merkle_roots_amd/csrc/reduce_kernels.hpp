@@ -126,12 +126,13 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
 #endif
 }
 
-// Top of the tree: up to VKMR_TAIL_MAX = 2048 nodes, exactly `levels` levels, one workgroup of
-// ceil(n/128) wavefronts (reduce_plan.hpp: tail_threads).  Level 1 comes from a coalesced pair load; the next
-// six levels stay inside each 64-lane wavefront with __shfl_down, exactly the shape of the reference's
-// subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377); up to sixteen wave results then meet in LDS and
-// wavefront 0 finishes with __shfl_down.  Any levels left once a single node remains hash that node with
-// itself ("keep iterating", README.md:94).
+// Top of the tree: the last <= 128 nodes, exactly `levels` levels, ONE wavefront.  Level 1 comes from a coalesced pair
+// load; the next six levels stay inside the wavefront with __shfl_down, exactly the shape of the reference's
+// subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377).  Any levels left once a single node remains hash that
+// node with itself ("keep iterating", README.md:94).
+// (Round 3 tried a 16-wavefront form for up to 2048 nodes, to save a launch: its wavefronts share one CU's four SIMDs
+// and each level costs 13.7 us against 9.4 us when reduce_collapse_kernel spreads them over the chip --
+// profiles/r03_reduce_top_kernels.txt -- so the schedule collapses down to 128 nodes again and this stays one wavefront.)
 __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0, uint32_t lane, uint64_t n_in,
                                                  uint32_t& done, uint32_t levels, uint32_t steps)
 {
@@ -155,52 +156,33 @@ __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0
     }
 }
 
-__global__ __launch_bounds__(VKMR_TAIL_MAX / 2) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
-                                                           Node* __restrict__ root0)
+__global__ __launch_bounds__(64) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                         Node* __restrict__ root0)
 {
     const uint32_t n_in = (uint32_t)slice_count(geom);
     const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
     Node* __restrict__ root = root0 + blockIdx.y * geom.out_stride;
-    __shared__ Node wave_out[16];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lane = threadIdx.x;
     uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t done = 0;
     if (levels == 0) {   // n_in == 1: the root is the node itself
-        if (tid == 0) *root = in[0];
+        if (lane == 0) *root = in[0];
         return;
     }
-    if (2 * tid < n_in) {
-        const Node a = vkmr_dev::load_node(in + 2 * tid);
-        const Node b = vkmr_dev::load_node(in + ((2 * tid + 1 < n_in) ? 2 * tid + 1 : 2 * tid));
+    if (2 * lane < n_in) {
+        const Node a = vkmr_dev::load_node(in + 2 * lane);
+        const Node b = vkmr_dev::load_node(in + ((2 * lane + 1 < n_in) ? 2 * lane + 1 : 2 * lane));
         vkmr_dev::hash_pair(a.w, b.w, X);
     }
-    done = 1;
-    shuffle_collapse(X, tid, lane, n_in, done, levels, 6);
-    if (blockDim.x > 64u && done < levels) {   // uniform across the workgroup: several wavefronts meet in LDS
-        if (lane == 0) {
+    uint32_t done = 1;
+    shuffle_collapse(X, lane, lane, n_in, done, levels, 6);
+    while (done < levels) {   // a single node left: pair it with itself (wave-uniform loop)
+        uint32_t o[8];
+        vkmr_dev::hash_pair(X, X, o);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wave_out[wave].w[i] = X[i];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            if (lane < 16u && lane < (blockDim.x >> 6)) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) X[i] = wave_out[lane].w[i];
-            }
-            shuffle_collapse(X, lane, lane, n_in, done, levels, 4);
-        }
+        for (int i = 0; i < 8; ++i) X[i] = o[i];
+        ++done;
     }
-    if (wave == 0) {
-        while (done < levels) {   // a single node left: pair it with itself (wave-uniform loop)
-            uint32_t o[8];
-            vkmr_dev::hash_pair(X, X, o);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) X[i] = o[i];
-            ++done;
-        }
-    }
-    if (tid == 0) vkmr_dev::store_node(root, X);
+    if (lane == 0) vkmr_dev::store_node(root, X);
 }
 
 // Middle of the tree, where there are too few nodes to keep every SIMD busy: one

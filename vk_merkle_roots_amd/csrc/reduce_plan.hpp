@@ -20,7 +20,8 @@
 #define VKMR_COLLAPSE_WAVES 1   // wavefronts per workgroup of reduce_collapse_kernel (4, "one per SIMD of a CU": 121 vs 111 us, profiles/r03_reduce_top_kernels.txt)
 #endif
 #ifndef VKMR_TAIL_MAX
-#define VKMR_TAIL_MAX 2048  // reduce_tail_kernel takes up to this many nodes: 1024 lanes = 16 wavefronts of one workgroup
+#define VKMR_TAIL_MAX 128   // reduce_tail_kernel takes up to this many nodes: 64 lanes, one wavefront (a 2048-node, 16-wavefront form
+                            // was measured slower than collapsing down to 128 first: profiles/r03_reduce_top_kernels.txt)
 #endif
 
 namespace vkmr_plan {
@@ -39,29 +40,18 @@ inline uint32_t pick_m(uint64_t n, uint32_t nslices)
 
 // One step of the reduction schedule for n nodes per slice with `left` levels to go:
 //   bulk     n/128 >= 2048 wavefronts: reduce_pass_kernel, m+1 levels, every lane busy
-//   tail     n <= TAIL_MAX (2048) and too few wavefronts for a bulk pass: reduce_tail_kernel, one workgroup of
-//            ceil(n/128) wavefronts, all remaining levels
+//   tail     n <= TAIL_MAX (128): reduce_tail_kernel, one wavefront, all remaining levels
 //   collapse otherwise: reduce_collapse_kernel, 7 levels, one wavefront per workgroup
 struct Step { int kind; uint32_t levels; uint64_t n_out; };
 enum { STEP_BULK = 0, STEP_COLLAPSE = 1, STEP_TAIL = 2 };
 
-// Lanes of the tail workgroup for n nodes: one per pair, whole wavefronts.
-inline uint32_t tail_threads(uint64_t n)
-{
-    const uint64_t pairs = (n + 1) >> 1;
-    const uint64_t t = (pairs + 63) & ~63ull;
-    return t < 64 ? 64u : (uint32_t)t;
-}
-
 inline Step next_step(uint64_t n, uint32_t left, uint32_t nslices)
 {
     Step st;
-    if (n <= 128) {
+    if (n <= VKMR_TAIL_MAX) {
         st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
     } else if (ceil_shift(n, 7) * nslices >= 2048) {   // many slices keep every lane busy even on short runs
         st.kind = STEP_BULK; st.levels = pick_m(n, nslices) + 1u; st.n_out = ceil_shift(n, st.levels);
-    } else if (n <= VKMR_TAIL_MAX) {
-        st.kind = STEP_TAIL; st.levels = left; st.n_out = 1;
     } else {
         st.kind = STEP_COLLAPSE; st.levels = 7; st.n_out = ceil_shift(n, 7);
     }
@@ -95,7 +85,7 @@ inline uint64_t cells_written(uint64_t n, uint32_t nslices)
 inline uint64_t cells_upper_bound(uint64_t count, uint32_t nslices)
 {
     if (nslices == 0) nslices = 1;
-    if (count <= 128) return 2;
+    if (count <= VKMR_TAIL_MAX) return 2;
     const uint64_t half = ceil_shift(count, 1);
     uint64_t small = ((1ull << 19) + nslices - 1) / nslices;   // the m < MAXM and collapse regimes
     if (small < 128) small = 128;

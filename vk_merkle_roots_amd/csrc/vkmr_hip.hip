@@ -417,7 +417,7 @@ static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32
         g.n_full = n; g.n_last = nl; g.in_stride = in_stride; g.nslices = nslices;
         if (st.kind == STEP_TAIL) {
             g.out_stride = 1;
-            hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(vkmr_plan::tail_threads(n)), 0, stream, in, g, left, roots);
+            hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(64), 0, stream, in, g, left, roots);
             VKMR_TRY(hipGetLastError());
             return VKMR_OK;
         }
