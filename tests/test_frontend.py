@@ -323,3 +323,23 @@ def test_hip_merkle_proof_folds_to_the_root(native, golden, env):
         assert proof and proof[0].split()[2] == str(index)
         assert proof[0].split()[-1] == hashlib.sha256(hashlib.sha256(leaves[index]).digest()).digest().hex()
         assert _fold_proof(proof) == s["root"], (index, env)
+
+
+@pytest.mark.gpu
+def test_packed_pipeline_entry_point_on_the_gpu(native, golden):
+    """vkmr_host_pipeline_packed (libvkmr_pipeline.so, what bench.py's pipeline_pcie_inclusive times): pre-packed strings
+    through the C++ stream processor -- copy stream, map stream, reductions, combine -- against the golden root of
+    rndm 42 2^20 127 (printed by the reference's CPU path), for a few batch and slice shapes."""
+    import ctypes as C
+    import vk_merkle_roots_amd as vk
+    from vk_merkle_roots_amd.build import PIPELINE_LIB
+    L = C.CDLL(PIPELINE_LIB)
+    L.vkmr_host_pipeline_packed.restype = C.c_int
+    L.vkmr_host_pipeline_packed.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.POINTER(C.c_double)]
+    want = golden["streams"]["G3_rndm_42_1048576_127"]["root"]
+    b = vk.rndm_packed(42, 1 << 20, 127)
+    for per_batch, slice_log2 in ((1 << 20, 0), (1 << 17, 18), (100000, 16), (1 << 18, 20)):
+        hexbuf, secs = C.create_string_buffer(65), C.c_double()
+        rc = L.vkmr_host_pipeline_packed(0, b.data.ctypes.data, b.words, b.meta.ctypes.data, b.count, per_batch, slice_log2, hexbuf, C.byref(secs))
+        assert rc == 0 and hexbuf.value.decode() == want, (per_batch, slice_log2, rc, hexbuf.value)
+        assert 0 < secs.value < 5

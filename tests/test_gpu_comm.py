@@ -31,6 +31,9 @@ def test_rccl_one_rank_init_all(gpu):
     vk.check(gpu.lib.vkmr_hip_comm_init_all(devs, 1, C.byref(comm)), "comm_init_all")
     roots = np.random.default_rng(1).integers(0, 2**32, size=(3, 8), dtype=np.uint32)
     assert (_gather_once(gpu, comm, 3, roots) == roots).all()
+    # which RCCL the communicator is bound to: a shared object that exists, and a version
+    info = gpu.lib.vkmr_hip_comm_info().decode()
+    assert info.startswith("rccl=/") and "librccl" in info and " version=" in info and int(info.rsplit("version=", 1)[1]) > 20000, info
     vk.check(gpu.lib.vkmr_hip_comm_destroy(comm), "comm_destroy")
 
 

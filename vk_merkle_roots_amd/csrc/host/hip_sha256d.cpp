@@ -132,6 +132,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
         for (auto& pd : m_devs)
             m_setup_ok = m_setup_ok && vkmr_hip_stream_create(pd.dev, &pd.copy_stream) == VKMR_OK &&
                          vkmr_hip_stream_create(pd.dev, &pd.reduce_stream) == VKMR_OK;
+        if (!m_setup_ok) m_setup_error = vkmr_hip_last_error();   // the ABI's error text is per thread: carry it over
     });
     m_pool.reset(new ForkJoin(cfg.pack_threads > 1 ? cfg.pack_threads - 1 : 0));
     m_mappings = Mappings::New(cfg.verbose);
@@ -212,7 +213,7 @@ void HipSha256D::Instance::JoinSetup()
     if (!m_setup.joinable()) return;
     m_setup.join();
     if (!m_setup_ok) {
-        std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
+        std::cerr << "Failed to initialise HIP streams: " << m_setup_error << std::endl;
         m_ok = false;
     }
 }

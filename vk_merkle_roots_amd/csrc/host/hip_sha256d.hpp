@@ -116,6 +116,7 @@ private:
     std::unique_ptr<class ForkJoin> m_pool;   // packs large input spans in parallel
     std::thread m_setup;                      // creates the streams the first batch does not need yet (hipStreamCreate: ~15 ms each)
     bool m_setup_ok = true;
+    std::string m_setup_error;
     bool m_ok;
     bool m_draining = false;   // Root() has begun: nothing more will be packed
     struct Staged { Batch batch; Slice sub; int dev; };

@@ -15,6 +15,8 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/vkmr_hip.h"
 #include "sha256d_device.hpp"
 
@@ -266,8 +268,8 @@ vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end,
 
 // What the last vkmr_hip_map_async of this process chose (reported by vkmr_hip_kernel_info).
 enum { MAP_NONE = 0, MAP_STAGED, MAP_DIRECT512, MAP_DIRECT256, MAP_EXPERIMENT };
-static int g_last_map_mode = MAP_NONE;
-static uint32_t g_last_map_tile = 0;
+static std::atomic<int> g_last_map_mode{MAP_NONE};       // diagnostics only; several host threads may drive different devices
+static std::atomic<uint32_t> g_last_map_tile{0};
 
 // The shipped fetch modes (csrc/map_kernel.hpp).  The mode is chosen from the batch alone:
 //   average packed string < 128 B   LDS-staged tiles (HBM traffic == algorithmic bytes)
@@ -361,7 +363,7 @@ const char* vkmr_hip_kernel_info(void)
 {
     static thread_local char buf[512];
     const char* map = "map=(no launch yet; staged: " VKMR_STR((VKMR_MAP_STAGED_KERNEL)) ")";
-    switch (g_last_map_mode) {
+    switch (g_last_map_mode.load()) {
         case MAP_STAGED: map = "map=" VKMR_STR((VKMR_MAP_STAGED_KERNEL)) " LDS-staged tiles sorted by block count"; break;
         case MAP_DIRECT512: map = "map=" VKMR_STR((VKMR_MAP_DIRECT512_KERNEL)) " per-lane 16-byte loads"; break;
         case MAP_DIRECT256: map = "map=" VKMR_STR((VKMR_MAP_DIRECT256_KERNEL)) " per-lane 16-byte loads, short launch"; break;
@@ -372,7 +374,7 @@ const char* vkmr_hip_kernel_info(void)
 #define VKMR_BUILD_ID "unknown"
 #endif
     snprintf(buf, sizeof buf, "%s tile=%u reduce=reduce_pass_kernel(m<=%d)+reduce_collapse_kernel+reduce_tail_kernel(<=%d nodes) build=" VKMR_BUILD_ID, map,
-             g_last_map_tile, VKMR_PASS_MAXM, VKMR_TAIL_MAX);
+             g_last_map_tile.load(), VKMR_PASS_MAXM, VKMR_TAIL_MAX);
     return buf;
 }
 
