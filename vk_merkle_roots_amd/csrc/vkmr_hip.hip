@@ -367,7 +367,9 @@ const char* vkmr_hip_kernel_info(void)
         case MAP_STAGED: map = "map=" VKMR_STR((VKMR_MAP_STAGED_KERNEL)) " LDS-staged tiles sorted by block count"; break;
         case MAP_DIRECT512: map = "map=" VKMR_STR((VKMR_MAP_DIRECT512_KERNEL)) " per-lane 16-byte loads"; break;
         case MAP_DIRECT256: map = "map=" VKMR_STR((VKMR_MAP_DIRECT256_KERNEL)) " per-lane 16-byte loads, short launch"; break;
+#ifdef VKMR_EXPERIMENTS
         case MAP_EXPERIMENT: map = "map=EXPERIMENT (VKMR_MAP_VARIANT; not a product build)"; break;
+#endif
         default: break;
     }
 #ifndef VKMR_BUILD_ID
