@@ -159,9 +159,12 @@ uint32_t HipSha256D::Instance::ChooseSliceLog2(const char* first_span, size_t le
     }
     const size_t budget = m_cfg.slice_budget ? m_cfg.slice_budget : m_cfg.max_inflight + 1;
     const double landing = (double)(m_cfg.max_inflight + 2) * ((double)m_cfg.batch_bytes * 1.25);   // data + metadata zones of the pipeline
-    double room = (free_min == ~(size_t)0) ? 0.0 : 0.85 * (double)free_min - landing;
-    uint32_t fits = 1;
-    while (fits < 40 && (double)((size_t)1 << (fits + 1)) * (32.0 * (double)budget + 12.0) <= room) ++fits;
+    uint32_t fits = 40;   // no memory figure from any device: nothing to clamp against (an allocation that fails is still reported)
+    if (free_min != ~(size_t)0) {
+        const double room = 0.85 * (double)free_min - landing;
+        fits = 1;
+        while (fits < 40 && (double)((size_t)1 << (fits + 1)) * (32.0 * (double)budget + 12.0) <= room) ++fits;
+    }
     uint32_t wanted = 23;
     *why = "the reference's 256 MiB slice (src/vkmr/SHA-256vk.cpp:23)";
     if (m_cfg.slice_log2_given) {
