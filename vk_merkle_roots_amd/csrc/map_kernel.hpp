@@ -32,8 +32,8 @@ using vkmr_dev::Node;
 //           lanes read LDS (the layout the north star describes).  Shipped for short
 //           strings: every byte crosses the HBM interface exactly once.
 //   MODE 2  four 16-byte loads per lane straight from HBM/L2 (strings are 4-byte aligned;
-//           gfx950 takes dword-aligned dwordx4).  No LDS, 7 waves/SIMD.  Shipped for long
-//           strings (>= 128 B on average); for short ones it is 1-2 % faster than MODE 0 but
+//           gfx950 takes dword-aligned dwordx4).  No LDS for data, 59 VGPRs: 8 waves/SIMD.  Shipped
+//           for strings >= 128 B on average; for short ones it is 1-2 % faster than MODE 0 but
 //           a 128-byte line shared by strings of different block counts is used at different
 //           times and re-fetched once it has left L2 (1.6x the algorithmic bytes at L2/fabric).
 //   MODE 1  per-wavefront gather: 16 lanes read one string's 64 contiguous bytes, four
