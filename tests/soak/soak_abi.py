@@ -6,7 +6,7 @@ import numpy as np, vk_merkle_roots_amd as vk
 from conftest import Oracle
 o = Oracle(); gpu = vk.HipDevice(0)
 rng = np.random.default_rng(int(time.time()))
-t0 = time.time(); cases = 0
+t0 = time.time(); cases = 0; last = t0
 while time.time() - t0 < (float(sys.argv[1]) if len(sys.argv) > 1 else 90):
     # random stream -> root via random slicing, both map modes via batched/unbatched engine paths
     n = int(rng.choice([rng.integers(1, 2000), rng.integers(1, 200000)]))
@@ -21,4 +21,6 @@ while time.time() - t0 < (float(sys.argv[1]) if len(sys.argv) > 1 else 90):
     got3 = vk.merkle_root_packed(gpu, b)
     assert got1 == want and got2 == want and got3 == want, (seed, n, maxlen, cap, bs)
     cases += 1
+    if time.time() - last > 60:   # a progress line a minute (a silent GPU run is taken to be hung after seven)
+        last = time.time(); print(f"... {cases} streams so far, all equal", flush=True)
 print("soak ok:", cases, "random streams, all roots equal the oracle")

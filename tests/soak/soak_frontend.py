@@ -20,6 +20,7 @@ virt = build_virt_devices()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(int(time.time()))
 t0 = time.time()
+last = t0
 cases = proofs = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.integers(1, 3000), rng.integers(1, 300000)]))
@@ -55,4 +56,7 @@ while time.time() - t0 < budget:
         assert cur.hex() == want, (seed, n, maxlen, backend, shape, proof_index)
         proofs += 1
     cases += 1
+    if time.time() - last > 60:   # a progress line a minute (a silent GPU run is taken to be hung after seven)
+        last = time.time()
+        print(f"... {cases} streams so far, all equal", flush=True)
 print("front-end soak ok:", cases, "random streams and pipeline shapes, all roots equal the oracle;", proofs, "random Merkle proofs fold to their root")
