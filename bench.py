@@ -316,7 +316,9 @@ def static_counts():
         return None
     hb = rec.get("hash_blocks", {})
     node = next((v[0] for k, v in hb.items() if "reduce_pass_kernel" in k and v), None)
-    out = {"build": rec.get("build"), "file": os.path.relpath(path, ROOT), "node": node, "map": {}}
+    out = {"build": rec.get("build"), "file": os.path.relpath(path, ROOT), "node": node, "map": {},
+           "issue_pass": {"prio_gap": rec.get("prio_gap"), "split_add3_every": rec.get("split_add3_every"),
+                          "complex_runs_raised": (rec.get("pass") or {}).get("runs"), "add3_split": (rec.get("pass") or {}).get("add3_split")}}
     for k, v in hb.items():
         if "map_kernel" in k and len(v) >= 2:
             m = k.split("map_kernelILi")[1].split("EEv")[0].replace("ELi", ", ").replace("ELb", ", ")
