@@ -48,3 +48,17 @@ def test_the_loaded_library_reports_the_id_of_the_sources_in_the_tree(native):
     assert provenance.build_id_of(info) == build.source_id()
     assert build.source_id(split_every=build.SPLIT_ADD3_EVERY + 1) != build.source_id()
     assert os.path.exists(os.path.splitext(build.HIP_LIB)[0] + ".isa.json")
+
+
+def test_experiment_only_sources_do_not_change_the_product_id(native, tmp_path, monkeypatch):
+    """map_experiments.hpp and csrc/experiments/ are compiled into the experiments build only: editing them must not
+    invalidate the records measured on the product library (and must change the experiments build's id)."""
+    from vk_merkle_roots_amd import build
+    product, exp = build.source_id(), build.source_id(["-DVKMR_EXPERIMENTS"])
+    csrc = tmp_path / "csrc"
+    shutil.copytree(build.CSRC, csrc)
+    with open(csrc / "map_experiments.hpp", "a") as f:
+        f.write("\n// another variant\n")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    assert build.source_id() == product
+    assert build.source_id(["-DVKMR_EXPERIMENTS"]) != exp

@@ -85,6 +85,8 @@ def source_id(defines=(), prio_gap=PRIO_GAP, split_every=SPLIT_ADD3_EVERY):
     for f in sorted(files):
         if os.sep + "host" + os.sep in f:
             continue            # host-side C++ is not in the kernel library
+        if "experiments" in os.path.relpath(f, CSRC) and "-DVKMR_EXPERIMENTS" not in defines:
+            continue            # map_experiments.hpp, experiments/*: compiled into the experiments build only
         feed(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             feed(fh.read())
