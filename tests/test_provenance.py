@@ -54,11 +54,17 @@ def test_experiment_only_sources_do_not_change_the_product_id(native, tmp_path, 
     """map_experiments.hpp and csrc/experiments/ are compiled into the experiments build only: editing them must not
     invalidate the records measured on the product library (and must change the experiments build's id)."""
     from vk_merkle_roots_amd import build
-    product, exp = build.source_id(), build.source_id(["-DVKMR_EXPERIMENTS"])
     csrc = tmp_path / "csrc"
     shutil.copytree(build.CSRC, csrc)
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    product, exp = build.source_id(), build.source_id(["-DVKMR_EXPERIMENTS"])   # of the copy (the id also covers the file order)
+    assert product != exp
     with open(csrc / "map_experiments.hpp", "a") as f:
         f.write("\n// another variant\n")
-    monkeypatch.setattr(build, "CSRC", str(csrc))
+    with open(csrc / "experiments" / "sha256d_lds.hpp", "a") as f:
+        f.write("\n// another form\n")
     assert build.source_id() == product
     assert build.source_id(["-DVKMR_EXPERIMENTS"]) != exp
+    with open(csrc / "map_kernel.hpp", "a") as f:
+        f.write("\n// the product's kernel\n")
+    assert build.source_id() != product
