@@ -91,6 +91,17 @@ VKMR_API vkmr_status vkmr_hip_memcpy_d2h_async(int dev, vkmr_stream s, void* dst
  * src/vkmr/Devices.cpp:525-538. */
 VKMR_API vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out);
 VKMR_API vkmr_status vkmr_hip_stream_destroy(int dev, vkmr_stream s);
+/* Start-up work, done when the caller wants it rather than inside its first copy and first launch: the library's
+ * kernels are loaded onto the device and the stream's queue comes up (VKMR_WARM_KERNELS: one launch of the map kernel on
+ * a four-byte string), the copy engine comes up (VKMR_WARM_COPY: one host-to-device copy of `copy_bytes` from pinned
+ * memory on the stream -- the engine's set-up depends on the size: give the size of the copies to come, at least 256);
+ * returns when both are done.  The reference pays the same at start-up, outside its stopwatch: ComputeDevice builds its
+ * shader modules and compute pipelines before run() begins (src/vkmr/Devices.cpp:225-280, Shaders.cpp:20-40).
+ * Optional: without it the first vkmr_hip_memcpy_h2d_async and the first launch take the time (20 + 15 ms on MI355X,
+ * profiles/r03_frontend_phases.txt). */
+#define VKMR_WARM_KERNELS 1u
+#define VKMR_WARM_COPY 2u
+VKMR_API vkmr_status vkmr_hip_warm_up(int dev, vkmr_stream s, unsigned what, size_t copy_bytes);
 VKMR_API vkmr_status vkmr_hip_stream_sync(int dev, vkmr_stream s);
 VKMR_API vkmr_status vkmr_hip_event_create(int dev, vkmr_event* out);
 VKMR_API vkmr_status vkmr_hip_event_destroy(int dev, vkmr_event e);

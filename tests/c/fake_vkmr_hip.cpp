@@ -183,6 +183,8 @@ vkmr_status vkmr_hip_memcpy_d2h_async(int, vkmr_stream, void* dst, const void* s
     return VKMR_OK;
 }
 
+vkmr_status vkmr_hip_warm_up(int dev, vkmr_stream, unsigned, size_t) { return dev_ok(dev) ? VKMR_OK : fail(VKMR_ERR_INVALID, "warm_up"); }
+
 vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
 {
     if (!out || !dev_ok(dev)) return fail(VKMR_ERR_INVALID, "stream_create");

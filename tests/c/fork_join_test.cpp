@@ -1,5 +1,5 @@
 // fork_join_test.cpp -- ThreadSanitizer check of the packer's fork-join pool and of the two-pass
-// parallel packing scheme on plain memory (built and run by tests/test_host_fuzz.py).
+// parallel packing scheme (IndexLines / PackIndexed, as Batch::PushLinesParallel runs them) on plain memory (built and run by tests/test_host_fuzz.py).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -43,11 +43,13 @@ int main()
         parts.push_back({lo, hi, {0, 0, 0, 0, false}});
         lo = hi;
     }
-    pool.Run(T, [&](unsigned t) { parts[t].c = CountLines(b + parts[t].lo, parts[t].hi - parts[t].lo); });
+    std::vector<LineIndex> index(T);
+    pool.Run(T, [&](unsigned t) { parts[t].c = IndexLines(b + parts[t].lo, parts[t].hi - parts[t].lo, &index[t]); });
     std::vector<size_t> w0(T), c0(T);
     size_t w = 0, c = 0;
     for (unsigned t = 0; t < T; ++t) { w0[t] = w; c0[t] = c; w += parts[t].c.words; c += parts[t].c.strings; }
-    pool.Run(T, [&](unsigned t) { PackLines(b + parts[t].lo, parts[t].hi - parts[t].lo, true, par.data(), w0[t], par.size(), mpar.data() + c0[t], parts[t].c.strings); });
+    // every part within its own words: the vector copies of one part must not reach into the next (another thread's)
+    pool.Run(T, [&](unsigned t) { PackIndexed(b + parts[t].lo, parts[t].hi - parts[t].lo, index[t], par.data(), w0[t], w0[t] + parts[t].c.words, mpar.data() + c0[t]); });
     if (c != rs.strings || w != rs.words) { printf("counts differ\n"); return 1; }
     if (memcmp(seq.data(), par.data(), w * 4) != 0 || memcmp(mseq.data(), mpar.data(), c * sizeof(vkmr_metadata)) != 0) { printf("packed data differ\n"); return 1; }
     printf("ok %zu strings %zu words\n", c, w);

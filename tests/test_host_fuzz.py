@@ -105,3 +105,36 @@ def test_avx2_line_splitter_equals_the_portable_one(native, parts, cap_words, ca
         outs.append((out.tolist(), data.tolist(), meta.tolist()))
     assert outs[0] == outs[1]
     assert outs[0][1][first_word + cap_words:] == [0xABABABAB] * 8      # nothing written past the capacity
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.lists(st.one_of(st.sampled_from([b"\n", b"\n\n", b"\r\n", b"x" * 63 + b"\n", b"y" * 64 + b"\n", b"z" * 65, b"q" * 200, b"\xff\x00",
+                                           b"p" * 127 + b"\n", b"r" * 128 + b"\n", b"s" * 129 + b"\n"]),
+                          st.binary(min_size=0, max_size=140)), max_size=60),
+       st.integers(0, 7))
+def test_indexed_two_pass_packer_equals_the_portable_one(native, parts, first_word):
+    """What the parallel packer runs on each part of a span -- pass 1 records where the lines end (four positions per 64-byte
+    block written whatever the count), pass 2 moves lines of up to 128 bytes as four vectors and clears the bytes behind
+    their ends -- must place the same words and metadata as the memchr-and-memcpy form, write nothing outside the words
+    pass 1 announced (the next words are another thread's part), and leave no stray byte in a string's last word."""
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    stream = b"".join(parts)
+    buf = np.frombuffer(stream, dtype=np.uint8) if stream else np.zeros(0, np.uint8)
+    ptr = buf.ctypes.data if len(stream) else None
+    cap_meta = stream.count(b"\n") + 1
+    cap_words = len(stream) // 4 + cap_meta + 1
+    ref_data = np.full(first_word + cap_words + 8, 0xABABABAB, dtype=np.uint32)
+    ref_meta = np.zeros((cap_meta + 1, 2), dtype=np.uint32)
+    ref = np.zeros(5, np.uint64)
+    h.vkmr_host_pack_prefix(ptr, len(stream), 1, ref_data.ctypes.data, first_word, first_word + cap_words, ref_meta.ctypes.data, cap_meta, 1, ref.ctypes.data)
+    consumed, strings, words, nbytes, empties = (int(v) for v in ref)
+    assert consumed == len(stream)
+    for which in (0, 1):
+        data = np.full(first_word + cap_words + 8, 0xABABABAB, dtype=np.uint32)
+        meta = np.zeros((cap_meta + 1, 2), dtype=np.uint32)
+        out = np.zeros(4, np.uint64)
+        got = h.vkmr_host_pack_indexed(ptr, len(stream), data.ctypes.data, first_word, first_word + cap_words, meta.ctypes.data, cap_meta, which, out.ctypes.data)
+        assert got == strings and [int(v) for v in out[:3]] == [words, nbytes, empties]
+        assert data.tolist() == ref_data.tolist()          # incl. the untouched words before first_word and from first_word + words on
+        assert meta.tolist() == ref_meta.tolist()

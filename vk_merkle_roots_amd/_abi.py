@@ -35,6 +35,7 @@ SIGNATURES = {
     "vkmr_hip_memcpy_h2d_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vkmr_hip_memcpy_d2h_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vkmr_hip_stream_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "vkmr_hip_warm_up": (C.c_int, [C.c_int, C.c_void_p, C.c_uint, C.c_size_t]),
     "vkmr_hip_stream_destroy": (C.c_int, [C.c_int, C.c_void_p]),
     "vkmr_hip_stream_sync": (C.c_int, [C.c_int, C.c_void_p]),
     "vkmr_hip_event_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -83,6 +84,7 @@ HOST_SIGNATURES = {
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vkmr_host_pack_lines_portable": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vkmr_host_pack_indexed": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "vkmr_host_count_lines": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "vkmr_host_pack_prefix": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
 }

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "fork_join.hpp"
+#include "timing.hpp"
 
 #include "stream_pack.hpp"
 
@@ -106,7 +107,7 @@ PackResult Batch::PushLines(const char* buf, size_t len, bool final, size_t max_
     return r;
 }
 
-PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, ForkJoin& pool)
+PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, ForkJoin& pool, double words_per_byte)
 {
     PackResult r = {0, 0, 0, 0, 0};
     const unsigned threads = pool.Width();
@@ -119,6 +120,26 @@ PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, siz
         usable = nl ? (size_t)(static_cast<const uint8_t*>(nl) - b) + 1 : 0;
     }
     if (usable < (1u << 20)) return r;
+    // What will not fit is not worth indexing: a span is cut to what the room left in the batch is likely to hold (the
+    // caller's words-per-byte figure of the stream so far, with 2 % to spare).  Without this a 64 MiB batch fed 32 MiB
+    // spans indexed every other span twice (profiles/r03_frontend_phases.txt: 172 index passes for 65 spans).
+    if (words_per_byte > 0.0) {
+        const double fits = (double)(m_cap_words - m_words) / words_per_byte * 0.98;
+        if (fits < (double)usable) {
+            if (fits < (double)(1u << 20)) return r;   // (nearly) full: the caller tops it up line by line, or sends it off
+            const void* nl = memrchr(b, '\n', (size_t)fits);
+            if (!nl) return r;
+            usable = (size_t)(static_cast<const uint8_t*>(nl) - b) + 1;
+        }
+    }
+    // parts are indexed with 32-bit offsets, and the index of a part is four times its size at worst (all lines empty):
+    // a very large span is taken in several calls (the caller comes back with the rest)
+    const size_t most = (size_t)threads << 26;
+    if (usable > most) {
+        const void* nl = memrchr(b, '\n', most);
+        if (!nl) return r;   // one line of more than 64 MiB x threads: the serial form deals with it
+        usable = (size_t)(static_cast<const uint8_t*>(nl) - b) + 1;
+    }
     // 1. parts that end after a '\n'
     struct Part { size_t lo, hi; LineCount c; };
     std::vector<Part> parts;
@@ -131,11 +152,22 @@ PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, siz
             const void* nl = memchr(b + hi, '\n', usable - hi);
             hi = nl ? (size_t)(static_cast<const uint8_t*>(nl) - b) + 1 : usable;
         }
-        if (hi > lo) parts.push_back({lo, hi, {0, 0, 0, 0, false}});
+        if (hi > lo) {
+            if (hi - lo >= 0xFFFFFF00ull) return r;   // (a single line that long)
+            parts.push_back({lo, hi, {0, 0, 0, 0, false}});
+        }
         lo = hi;
     }
-    // 2. measure every part
-    pool.Run((unsigned)parts.size(), [&](unsigned t) { parts[t].c = CountLines(b + parts[t].lo, parts[t].hi - parts[t].lo); });
+    // 2. index every part: where its lines end, and what it will append
+    static thread_local std::vector<LineIndex> kept;   // from span to span, one per part
+    if (kept.size() < parts.size()) kept.resize(parts.size());
+    LineIndex* const index = kept.data();   // (a thread_local named inside the tasks would be each worker's own, empty, vector)
+    {
+        timing::Scope ts(timing::INDEX);
+        pool.Run((unsigned)parts.size(), [&](unsigned t) { parts[t].c = IndexLines(b + parts[t].lo, parts[t].hi - parts[t].lo, index + t); });
+    }
+    for (size_t t = 0; t < parts.size(); ++t)
+        if (!index[t].ends) return r;   // out of memory for an index: the serial form needs none
     // 3. leading parts that fit entirely
     size_t room = m_cap_count - m_count;
     if (room > max_strings) room = max_strings;
@@ -143,8 +175,7 @@ PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, siz
     std::vector<size_t> w0, c0;
     for (; k < parts.size(); ++k) {
         const LineCount& c = parts[k].c;
-        if (c.too_long || strings + c.strings > room || m_words + words + c.words > m_cap_words ||
-            m_words + words + c.words > 0xFFFFFFFFull)
+        if (strings + c.strings > room || m_words + words + c.words > m_cap_words || m_words + words + c.words > 0xFFFFFFFFull)
             break;
         w0.push_back(m_words + words);
         c0.push_back(m_count + strings);
@@ -152,10 +183,13 @@ PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, siz
         strings += c.strings;
     }
     if (k == 0) return r;
-    // 4. pack them at their prefix offsets
-    pool.Run((unsigned)k, [&](unsigned t) {
-        PackLines(b + parts[t].lo, parts[t].hi - parts[t].lo, true, m_data, w0[t], m_cap_words, m_meta + c0[t], parts[t].c.strings);
-    });
+    // 4. pack them at their prefix offsets, each within its own words
+    {
+        timing::Scope ts(timing::PACK);
+        pool.Run((unsigned)k, [&](unsigned t) {
+            PackIndexed(b + parts[t].lo, parts[t].hi - parts[t].lo, index[t], m_data, w0[t], w0[t] + parts[t].c.words, m_meta + c0[t]);
+        });
+    }
     for (size_t t = 0; t < k; ++t) {
         r.bytes += parts[t].c.bytes;
         r.empties += parts[t].c.empties;

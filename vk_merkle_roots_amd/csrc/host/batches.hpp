@@ -45,6 +45,8 @@ public:
     size_type Size() const { return m_bytes; }           // payload bytes
     size_type Words() const { return m_words; }          // packed words used
     bool Empty() const { return !(*this) || m_count == 0; }
+    size_type RoomWords() const { return m_cap_words - m_words; }     // packed words still free
+    size_type CapacityWords() const { return m_cap_words; }
     number_type Number() const { return m_number; }
     int Device() const { return m_dev; }
 
@@ -60,8 +62,10 @@ public:
     // ends, the parts are measured in parallel, the leading parts that fit the batch (and
     // `max_strings`) are packed in parallel at their prefix offsets.  Returns what was consumed
     // and appended (possibly nothing: the caller then falls back to PushLines).  Every part
-    // but the last of a final span ends in '\n'.
-    struct PackResult PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, class ForkJoin& pool);
+    // but the last of a final span ends in '\n'.  No more of the span is looked at than the batch is likely to hold:
+    // `words_per_byte` is the caller's running figure of packed words per input byte (0 = unknown).
+    struct PackResult PushLinesParallel(const char* buf, size_t len, bool final, size_t max_strings, class ForkJoin& pool,
+                                        double words_per_byte = 0.0);
     // Appends strings that are already in the packed layout (consecutive, canonical: string i + 1 starts on the word after
     // string i): one memcpy of their words, metadata rebased onto this batch.  Takes as many of the `count` strings as fit
     // (and at most `max_strings`); returns how many.

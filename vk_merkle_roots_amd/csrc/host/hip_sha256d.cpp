@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "fork_join.hpp"
+#include "timing.hpp"
 #include "util.hpp"
 
 namespace vkmr {
@@ -111,8 +112,13 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
     for (int d : devices) {
         PerDevice pd;
         pd.dev = d;
-        m_ok = m_ok && vkmr_hip_stream_create(d, &pd.map_stream) == VKMR_OK;
-        pd.batches.reset(new Batches(d, cfg.batch_bytes));
+        // an input of known size that one batch holds gets a batch of that size (pinning 80 MiB for a few strings is 13 ms)
+        size_t batch_bytes = cfg.batch_bytes;
+        if (cfg.expected_input_bytes > 0) {
+            const uint64_t need = ((cfg.expected_input_bytes + cfg.expected_input_bytes / 4 + (1u << 16)) + ((1u << 20) - 1)) & ~(uint64_t)((1u << 20) - 1);
+            if (need < batch_bytes) batch_bytes = (size_t)need;
+        }
+        pd.batches.reset(new Batches(d, batch_bytes));
         if (cfg.verbose) {
             char devname[256] = "";
             size_t free_b = 0, total_b = 0;
@@ -125,18 +131,46 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
         }
         m_devs.push_back(std::move(pd));
     }
-    // The first batch needs the map stream only once it is packed, the copy stream with it, the reduce stream when the
-    // first slice is full: the latter two are made on a helper thread while this one starts reading (each hipStreamCreate
-    // is 10-15 ms of a run that takes 150 ms for 2^25 strings: profiles/r02_hip_api_stats_256_slices.csv).
-    m_setup = std::thread([this] {
-        for (auto& pd : m_devs)
-            m_setup_ok = m_setup_ok && vkmr_hip_stream_create(pd.dev, &pd.copy_stream) == VKMR_OK &&
-                         vkmr_hip_stream_create(pd.dev, &pd.reduce_stream) == VKMR_OK;
-        if (!m_setup_ok) m_setup_error = vkmr_hip_last_error();   // the ABI's error text is per thread: carry it over
-    });
+    // Streams, and the start-up work the runtime would otherwise do inside the first copy and the first launch (the
+    // kernels loaded onto the device: 15-20 ms; the copy engine brought up: 8-20 ms; a stream: 5-15 ms).  All of it is
+    // done before the constructor returns: like the reference, whose devices build their shader modules and pipelines
+    // before run() starts its stopwatch (src/vkmr/Devices.cpp:225-280).  Measured on one device
+    // (profiles/r03_frontend_setup_orders.txt): these calls and the pinning of the batches serialise inside the driver
+    // whatever threads issue them, so one device is set up on this thread; several devices get a thread each.
+    // Reductions share the map stream: a third stream is another 10-15 ms, and the GPU of a pipeline fed over PCIe is idle
+    // nine tenths of the time (the two-stream overlap pays only for resident data: bench.py, two_stream_overlap).
+    auto failed = [this](const char* what) {
+        std::lock_guard<std::mutex> lock(m_setup_mu);
+        if (m_setup_ok) m_setup_error = std::string(what) + ": " + vkmr_hip_last_error();   // the ABI's error text is per thread: carry it over
+        m_setup_ok = false;
+    };
+    const size_t warm_bytes = (size_t)1 << 20;   // a copy the engine treats like a batch's: after a 256-byte one the first batch still took 8-19 ms to submit,
+                                                 // after 64 KiB and more 0.01 ms (profiles/r03_frontend_warm_copy.txt)
+    auto set_up = [failed, warm_bytes](PerDevice* p) {
+        if (vkmr_hip_stream_create(p->dev, &p->map_stream) != VKMR_OK || vkmr_hip_warm_up(p->dev, p->map_stream, VKMR_WARM_KERNELS, 0) != VKMR_OK)
+            return failed("map stream");
+        if (vkmr_hip_stream_create(p->dev, &p->copy_stream) != VKMR_OK || vkmr_hip_warm_up(p->dev, p->copy_stream, VKMR_WARM_COPY, warm_bytes) != VKMR_OK)
+            return failed("copy stream");
+        p->reduce_stream = p->map_stream;
+    };
+    for (int d : m_device_ids) {   // what the devices have free now, before this instance takes any of it (ChooseSliceLog2)
+        size_t f = 0, t = 0;
+        if (vkmr_hip_device_mem_info(d, &f, &t) == VKMR_OK && f < m_free_at_start) m_free_at_start = f;
+    }
+    StartPrefetch();   // the first device's batches, on its pool's helper thread: ready, or nearly, when the first span arrives
+    if (m_devs.size() == 1) {
+        set_up(&m_devs.front());
+    } else {
+        std::vector<std::thread> threads;
+        for (auto& pd : m_devs) threads.emplace_back(set_up, &pd);
+        for (auto& t : threads) t.join();
+    }
+    if (!m_setup_ok) {
+        std::cerr << "Failed to initialise HIP streams: " << m_setup_error << std::endl;
+        m_ok = false;
+    }
     m_pool.reset(new ForkJoin(cfg.pack_threads > 1 ? cfg.pack_threads - 1 : 0));
     m_mappings = Mappings::New(cfg.verbose);
-    if (!m_ok) std::cerr << "Failed to initialise HIP streams: " << vkmr_hip_last_error() << std::endl;
     // slices and reductions are made when the first strings arrive: their size is chosen then (EnsureGeometry)
 }
 
@@ -152,11 +186,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
 // The result is min(wanted, fits); a given value that does not fit is clamped with a message instead of failing in hipMalloc.
 uint32_t HipSha256D::Instance::ChooseSliceLog2(const char* first_span, size_t len, std::string* why) const
 {
-    size_t free_min = ~(size_t)0;
-    for (int d : m_device_ids) {
-        size_t f = 0, t = 0;
-        if (vkmr_hip_device_mem_info(d, &f, &t) == VKMR_OK && f < free_min) free_min = f;
-    }
+    const size_t free_min = m_free_at_start;   // read before the first batch was pinned: `landing` below counts every batch
     const size_t budget = m_cfg.slice_budget ? m_cfg.slice_budget : m_cfg.max_inflight + 1;
     const double landing = (double)(m_cfg.max_inflight + 2) * ((double)m_cfg.batch_bytes * 1.25);   // data + metadata zones of the pipeline
     uint32_t fits = 40;   // no memory figure from any device: nothing to clamp against (an allocation that fails is still reported)
@@ -211,19 +241,23 @@ bool HipSha256D::Instance::EnsureGeometry(const char* first_span, size_t len)
     return m_ok;
 }
 
-void HipSha256D::Instance::JoinSetup()
+// The batches of the first device's pipeline are pinned on its helper thread from now on, not when the first strings
+// arrive: as many as the input will fill when its size is known, else one (the rest follow when that one goes out full).
+void HipSha256D::Instance::StartPrefetch()
 {
-    if (!m_setup.joinable()) return;
-    m_setup.join();
-    if (!m_setup_ok) {
-        std::cerr << "Failed to initialise HIP streams: " << m_setup_error << std::endl;
-        m_ok = false;
+    if (!m_ok || m_devs.empty()) return;
+    PerDevice& pd = m_devs.front();
+    size_t want = 1;
+    if (m_cfg.expected_input_bytes > 0) {
+        want = (size_t)((m_cfg.expected_input_bytes + m_cfg.expected_input_bytes / 16) / pd.batches->DataBytes()) + 1;
+        if (want > m_cfg.max_inflight + 1) want = m_cfg.max_inflight + 1;
     }
+    pd.batches->Prefetch(want);
+    pd.prefetched = want > 1;
 }
 
 HipSha256D::Instance::~Instance()
 {
-    JoinSetup();
     // ops first (they hold batches and slices), then the pools and streams
     m_pool.reset();
     m_mappings.reset();
@@ -234,7 +268,7 @@ HipSha256D::Instance::~Instance()
         pd.batches.reset();
         vkmr_hip_stream_destroy(pd.dev, pd.map_stream);
         vkmr_hip_stream_destroy(pd.dev, pd.copy_stream);
-        vkmr_hip_stream_destroy(pd.dev, pd.reduce_stream);
+        if (pd.reduce_stream != pd.map_stream) vkmr_hip_stream_destroy(pd.dev, pd.reduce_stream);
     }
 }
 
@@ -256,7 +290,7 @@ void HipSha256D::Instance::Account(std::vector<Slice>&& retired)
         if (slice.IsFilled()) {
             if (m_cfg.verbose) std::cout << "Slice #" << slice.Number() << " has been filled." << std::endl;
             const int dev = slice.Device();
-            if (m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, (JoinSetup(), Dev(dev).reduce_stream)) != VKMR_OK) m_ok = false;
+            if (m_reductions->Reduce(m_slices.Remove(sub.Number()), m_cfg.slice_log2, Dev(dev).reduce_stream) != VKMR_OK) m_ok = false;
         }
     }
     if (m_mappings->Failed()) m_ok = false;
@@ -277,6 +311,7 @@ bool HipSha256D::Instance::WaitForMemory()
 
 bool HipSha256D::Instance::NewBatch(int dev)
 {
+    timing::Scope ts(timing::BATCH);
     for (;;) {
         m_batch = Dev(dev).batches->New();
         if (m_batch) return true;
@@ -310,8 +345,11 @@ bool HipSha256D::Instance::MapCurrent()
 {
     Slice& slice = m_slices.Current();
     if (m_batch.Empty() || !slice) return true;
-    if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
-    JoinSetup();   // the copy stream is needed from here on
+    if (m_mappings->InFlight() >= m_cfg.max_inflight) {
+        timing::Scope tw(timing::MAP_WAIT);
+        Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
+    }
+    timing::Scope ts(timing::MAP);
     PerDevice& pd = Dev(slice.Device());
     AdaptBatchSize(m_batch);
     if (!pd.prefetched && !m_draining && m_batch.Words() * 4 >= pd.batches->DataBytes() / 2) {
@@ -329,6 +367,7 @@ bool HipSha256D::Instance::StartSliceAndBatch()
     // reduction to retire and take over its slice, instead of halting (reference SHA-256vk.cpp:396-399
     // halts; README.md:113 is the to-do this implements)
     for (;;) {
+        timing::Scope ts(timing::SLICE);
         bool budget_hit = false;
         Slice& slice = m_slices.New(&budget_hit);
         if (slice) break;
@@ -387,8 +426,11 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
     if (!m_ok || !EnsureGeometry(buf, len)) return false;
     size_t pos = 0;
     while (pos < len) {
-        m_reductions->Update();
-        if (m_mappings->InFlight()) Account(m_mappings->Update());
+        {
+            timing::Scope ts(timing::UPDATE);
+            m_reductions->Update();
+            if (m_mappings->InFlight()) Account(m_mappings->Update());
+        }
         if (!m_ok || !m_reductions->Ok()) return (m_ok = false);   // a mapping or reduction failed on the device: stop reading
         if (!m_slices.Current()) {
             if (!StartSliceAndBatch()) return false;
@@ -396,9 +438,25 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
             if (!MapCurrent()) return (m_ok = false);
             if (!StartSliceAndBatch()) return false;
         }
+        if (!m_batch.Empty() && len - pos >= (1u << 20)) {
+            // A large span is waiting.  A batch that is full but for a sliver goes out as it is (topping it up line by line
+            // would be done on this thread while the packer's other threads wait); so does a batch that holds a good part of
+            // its capacity when the rest of the span will not fit: whole spans pack with one fork-join pair, cut ones with
+            // two, and a default batch is made to hold one span of stdin (HipConfig::batch_bytes).
+            const size_t room = m_batch.RoomWords(), cap = m_batch.CapacityWords();
+            const double needs = (double)(len - pos) * (m_words_per_byte > 0.0 ? m_words_per_byte : 0.26) * 1.02;
+            if (room < cap / 32 || (needs > (double)room && cap - room >= cap / 4)) {
+                const int dev = m_slices.Current().Device();
+                if (!MapCurrent() || !NewBatch(dev)) return (m_ok = false);
+            }
+        }
         Slice& slice = m_slices.Current();
-        PackResult r = m_batch.PushLinesParallel(buf + pos, len - pos, final, slice.Available(), *m_pool);
-        if (r.consumed == 0) r = m_batch.PushLines(buf + pos, len - pos, final, slice.Available());
+        PackResult r = m_batch.PushLinesParallel(buf + pos, len - pos, final, slice.Available(), *m_pool, m_words_per_byte);
+        if (r.consumed >= (1u << 20)) m_words_per_byte = (double)r.words / (double)r.consumed;
+        if (r.consumed == 0) {
+            timing::Scope ts(timing::PACK_SERIAL);
+            r = m_batch.PushLines(buf + pos, len - pos, final, slice.Available());
+        }
         slice.Reserve(r.strings);
         tally->items += r.strings;
         tally->bytes += r.bytes;
@@ -492,7 +550,6 @@ ISha256D::out_type HipSha256D::Instance::RootOfStaged()
             m_staged.push_back(std::move(st));
         }
     }
-    JoinSetup();
     for (auto& st : m_staged) {
         m_reductions->Update();
         if (m_mappings->InFlight()) Account(m_mappings->Update());
@@ -510,9 +567,13 @@ ISha256D::out_type HipSha256D::Instance::Root()
     // residual batch, then every mapping (reference SHA-256vk.cpp:291-299)
     m_draining = true;
     const bool single = m_slices.LastNumber() <= 1;
-    if (!MapCurrent()) return "";
-    Account(m_mappings->WaitFor());
+    {
+        timing::Scope ts(timing::DRAIN_MAP);
+        if (!MapCurrent()) return "";
+        Account(m_mappings->WaitFor());
+    }
     if (!m_ok) return "";   // a mapping or a reduction failed: there is no root
+    timing::Scope ts(timing::DRAIN_REDUCE);
     // every remaining slice (at most the last, partial one): slice #1 alone is
     // reduced over its own count, any other to full capacity height
     // (reference Reductions.cpp:471; SHA-256vk.cpp:301-311)
@@ -523,7 +584,6 @@ ISha256D::out_type HipSha256D::Instance::Root()
         if (!s || s.Count() == 0) continue;
         const uint32_t height = (single && number == 1) ? tree_height(s.Count()) : m_cfg.slice_log2;
         const int dev = s.Device();
-        JoinSetup();
         if (m_reductions->Reduce(std::move(s), height, Dev(dev).reduce_stream) != VKMR_OK) return "";
     }
     const out_type root = m_reductions->WaitFor();

@@ -9,6 +9,7 @@
 #pragma once
 #include <memory>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -25,13 +26,16 @@ struct HipConfig {
                                      // sets it; a value that does not fit is clamped with a message
     bool slice_log2_given = false;   // slice_log2 came from the caller (VKMR_SLICE_LOG2), not from the default
     uint64_t expected_input_bytes = 0;  // bytes stdin will deliver when that is known (a regular file), else 0
-    size_t batch_bytes = 64u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
-                                     // :247-248); fed from stdin, 32-64 MiB batches pipeline best on MI355X (copies
-                                     // and kernels hide behind the host packer; measured sweep in DESIGN.md 5)
+    size_t batch_bytes = 40u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
+                                     // :247-248).  Here a batch holds one 32 MiB span of stdin (vkmr_main) with room for
+                                     // the padding of short lines; pinning it (50 MiB with its metadata) is 8 ms, and
+                                     // all of the pipeline's batches are pinned before the first string is read
+                                     // (profiles/r03_frontend_phases.txt)
     size_t batch_bytes_max = 1u << 30;  // long strings: batches grow until they hold about 2^19 strings, up to this many
                                      // bytes (a 64 MiB batch of 2 KiB strings is 32 k strings = 512 wavefronts for
                                      // 1024 SIMDs; the map kernel needs >= ~0.5 M strings per launch to fill the chip)
-    size_t max_inflight = 4;         // mappings in flight before Add() blocks on the oldest
+    size_t max_inflight = 3;         // mappings in flight before Add() blocks on the oldest (the pipeline is PCIe-bound: one
+                                     // batch being packed, one being copied, one in the kernel, one to spare)
     size_t slice_budget = 0;         // slices resident per device at most (0 = max_inflight + 1: the one being filled
                                      // plus one per mapping in flight); when used up, Add() blocks on the oldest
                                      // reduction and re-uses its slice instead of allocating another
@@ -89,12 +93,12 @@ public:
 private:
     struct PerDevice {
         int dev;
-        vkmr_stream map_stream = nullptr, copy_stream = nullptr, reduce_stream = nullptr;
+        vkmr_stream map_stream = nullptr, copy_stream = nullptr, reduce_stream = nullptr;   // reduce_stream is the map stream (see the constructor)
         std::unique_ptr<Batches> batches;
         bool prefetched = false;   // the pipeline's batches have been requested from the helper thread
     };
     PerDevice& Dev(int dev);
-    void JoinSetup();                                    // the copy and reduce streams are created on a helper thread: wait for it
+    void StartPrefetch();                                // the first device's batches start being pinned on its pool's helper thread
     bool EnsureGeometry(const char* first_span, size_t len);   // slices and reductions exist from the first string on
     uint32_t ChooseSliceLog2(const char* first_span, size_t len, std::string* why) const;
     bool MapCurrent();                                   // dispatches m_batch into the current slice's pending reservations
@@ -114,11 +118,13 @@ private:
     std::unique_ptr<Mappings> m_mappings;
     std::unique_ptr<Reductions> m_reductions;
     std::unique_ptr<class ForkJoin> m_pool;   // packs large input spans in parallel
-    std::thread m_setup;                      // creates the streams the first batch does not need yet (hipStreamCreate: ~15 ms each)
+    std::mutex m_setup_mu;                    // several devices are set up side by side: the first error is kept
     bool m_setup_ok = true;
     std::string m_setup_error;
     bool m_ok;
     bool m_draining = false;   // Root() has begun: nothing more will be packed
+    size_t m_free_at_start = ~(size_t)0;   // least free memory over the devices when the instance was made (~0: no device said)
+    double m_words_per_byte = 0.0;   // packed words per input byte of the spans packed so far (how much of a span a batch will hold)
     struct Staged { Batch batch; Slice sub; int dev; };
     std::vector<Staged> m_staged;
 };

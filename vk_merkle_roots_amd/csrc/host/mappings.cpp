@@ -4,6 +4,7 @@
 #include <iostream>
 
 #include "ops.hpp"
+#include "timing.hpp"
 
 namespace vkmr {
 namespace {
@@ -41,18 +42,23 @@ public:
             return VKMR_ERR_HIP;
         }
         HipResult r = vkmr_hip_event_record(m.dev, m.begin, copy_stream);
-        if (r == VKMR_OK)
-            r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
-        if (r == VKMR_OK)
-            r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceMeta(), batch.HostMeta(),
-                                          batch.Count() * sizeof(vkmr_metadata));
+        {
+            timing::Scope ts(timing::MAP_COPIES);
+            if (r == VKMR_OK)
+                r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
+            if (r == VKMR_OK)
+                r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceMeta(), batch.HostMeta(),
+                                              batch.Count() * sizeof(vkmr_metadata));
+        }
         if (r == VKMR_OK && copy_stream != stream) {
             r = vkmr_hip_event_record(m.dev, m.copied, copy_stream);
             if (r == VKMR_OK) r = vkmr_hip_stream_wait_event(m.dev, stream, m.copied);
         }
-        if (r == VKMR_OK)
+        if (r == VKMR_OK) {
+            timing::Scope ts(timing::MAP_LAUNCH);
             r = vkmr_hip_map_async(m.dev, stream, batch.DeviceData(), batch.Words(), batch.DeviceMeta(),
                                    (uint32_t)batch.Count(), sub.Cells());
+        }
         if (r == VKMR_OK) r = vkmr_hip_event_record(m.dev, m.done, stream);
         if (r != VKMR_OK) {
             std::cerr << "Failed to dispatch a mapping: " << vkmr_hip_last_error() << std::endl;

@@ -64,6 +64,81 @@ LineCount CountLinesPortable(const uint8_t* buf, size_t len)
     return c;
 }
 
+// ---- indexed two-pass form, portable ------------------------------------------------------------------------
+
+LineIndex::~LineIndex() { free(ends); }
+
+void LineIndex::Reserve(size_t lines)
+{
+    count = 0;
+    if (lines + 16 <= cap) return;
+    free(ends);
+    cap = lines + 16;
+    ends = static_cast<uint32_t*>(malloc(cap * sizeof(uint32_t)));   // not touched until written: a part of long lines uses a page of it
+    if (!ends) cap = 0;
+}
+
+namespace {
+
+// What the lines of an index add up to.  Line i spans (ends[i-1], ends[i]); the first starts at 0.
+LineCount totals_of(const LineIndex& ix)
+{
+    LineCount c = {0, 0, 0, 0, false};
+    const uint32_t* e = ix.ends;
+    const size_t k = ix.count;
+    if (k == 0) return c;
+    uint64_t strings = e[0] != 0, words = ((uint64_t)e[0] + 3u) >> 2;
+    for (size_t i = 1; i < k; ++i) {
+        const uint32_t n = e[i] - e[i - 1] - 1u;
+        strings += n != 0;
+        words += (n + 3u) >> 2;
+    }
+    c.strings = strings;
+    c.words = words;
+    c.bytes = (uint64_t)e[k - 1] + 1u - k;   // every line but its newline
+    c.empties = k - strings;
+    return c;
+}
+
+}  // namespace
+
+LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix)
+{
+    ix->Reserve(len + 1);
+    uint32_t* o = ix->ends;
+    size_t pos = 0;
+    while (pos < len) {
+        const uint8_t* nl = static_cast<const uint8_t*>(memchr(buf + pos, '\n', len - pos));
+        const size_t end = nl ? (size_t)(nl - buf) : len;
+        *o++ = (uint32_t)end;
+        pos = end + 1;
+    }
+    ix->count = (size_t)(o - ix->ends);
+    return totals_of(*ix);
+}
+
+void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
+                         vkmr_metadata* meta)
+{
+    (void)len; (void)end_word;
+    uint64_t w = first_word;
+    size_t s = 0;
+    uint32_t start = 0;
+    for (size_t i = 0; i < ix.count; ++i) {
+        const uint32_t n = ix.ends[i] - start;
+        if (n) {
+            const uint32_t nw = (n + 3u) >> 2;
+            meta[s].start = (uint32_t)w;
+            meta[s].size = n;
+            ++s;
+            data[w + nw - 1] = 0u;
+            memcpy(data + w, buf + start, n);
+            w += nw;
+        }
+        start = ix.ends[i] + 1u;
+    }
+}
+
 namespace {
 
 // ---- AVX2 forms: the newlines of 64 input bytes at a time -----------------------------------------------------
@@ -154,9 +229,81 @@ __attribute__((target("avx2"))) PackResult PackLinesAvx2(const uint8_t* buf, siz
     return r;
 }
 
+// Pass 1 of the indexed form.  The walk over the set bits of a block's newline mask is what the line-at-a-time loops
+// above mispredict on (0 to 3 newlines per 64 bytes of a rndm stream, at random): here four positions are written
+// whatever the count -- tzcnt of an exhausted mask gives 64, a value that the next block overwrites -- and the output
+// advances by the population count.
+__attribute__((target("avx2,bmi,popcnt"))) LineCount IndexLinesAvx2(const uint8_t* buf, size_t len, LineIndex* ix)
+{
+    ix->Reserve(len + 1);
+    uint32_t* o = ix->ends;
+    size_t blk = 0;
+    for (; blk + 64 <= len; blk += 64) {
+        uint64_t m = newline_mask64(buf + blk);
+        const unsigned cnt = (unsigned)__builtin_popcountll(m);
+        const uint32_t base = (uint32_t)blk;
+        o[0] = base + (uint32_t)_tzcnt_u64(m); m = _blsr_u64(m);
+        o[1] = base + (uint32_t)_tzcnt_u64(m); m = _blsr_u64(m);
+        o[2] = base + (uint32_t)_tzcnt_u64(m); m = _blsr_u64(m);
+        o[3] = base + (uint32_t)_tzcnt_u64(m); m = _blsr_u64(m);
+        if (__builtin_expect(cnt > 4, 0)) {
+            for (unsigned k = 4; k < cnt; ++k) {
+                o[k] = base + (uint32_t)_tzcnt_u64(m);
+                m = _blsr_u64(m);
+            }
+        }
+        o += cnt;
+    }
+    for (size_t i = blk; i < len; ++i)
+        if (buf[i] == '\n') *o++ = (uint32_t)i;
+    if (len > 0 && buf[len - 1] != '\n') *o++ = (uint32_t)len;   // the unterminated last line
+    ix->count = (size_t)(o - ix->ends);
+    return totals_of(*ix);
+}
+
+// Pass 2.  A line of up to 128 bytes is moved as four 32-byte vectors whatever its length -- what lands behind its end
+// is overwritten by the next line, and the bytes of its last word beyond its end are cleared afterwards -- as long as
+// that stays inside this part's input and this part's words; longer lines, and the last few of a part, go through memcpy.
+__attribute__((target("avx2"))) void PackIndexedAvx2(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word,
+                                                     uint64_t end_word, vkmr_metadata* meta)
+{
+    uint64_t w = first_word;
+    vkmr_metadata* mo = meta;
+    uint32_t start = 0;
+    const uint32_t* ends = ix.ends;
+    for (size_t i = 0; i < ix.count; ++i) {
+        const uint32_t e = ends[i];
+        const uint32_t n = e - start;
+        if (n) {
+            const uint32_t nw = (n + 3u) >> 2;
+            mo->start = (uint32_t)w;
+            mo->size = n;
+            ++mo;
+            const uint8_t* src = buf + start;
+            uint8_t* dst = reinterpret_cast<uint8_t*>(data + w);
+            if (n <= 128u && (size_t)start + 128u <= len && w + 32u <= end_word) {
+                const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src));
+                const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32));
+                const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 64));
+                const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 96));
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst), a);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 32), b);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 64), c);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 96), d);
+                data[w + nw - 1] &= 0xFFFFFFFFu >> (8u * ((0u - n) & 3u));
+            } else {
+                data[w + nw - 1] = 0u;
+                memcpy(dst, src, n);
+            }
+            w += nw;
+        }
+        start = e + 1u;
+    }
+}
+
 bool have_avx2()
 {
-    static const bool yes = __builtin_cpu_supports("avx2") && !getenv("VKMR_NO_AVX2");
+    static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt") && !getenv("VKMR_NO_AVX2");
     return yes;
 }
 #endif
@@ -178,6 +325,22 @@ LineCount CountLines(const uint8_t* buf, size_t len)
     if (have_avx2()) return CountLinesAvx2(buf, len);
 #endif
     return CountLinesPortable(buf, len);
+}
+
+LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix)
+{
+#ifdef VKMR_HAVE_AVX2_PATH
+    if (have_avx2()) return IndexLinesAvx2(buf, len, ix);
+#endif
+    return IndexLinesPortable(buf, len, ix);
+}
+
+void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word, vkmr_metadata* meta)
+{
+#ifdef VKMR_HAVE_AVX2_PATH
+    if (have_avx2()) return PackIndexedAvx2(buf, len, ix, data, first_word, end_word, meta);
+#endif
+    PackIndexedPortable(buf, len, ix, data, first_word, end_word, meta);
 }
 
 }  // namespace vkmr
@@ -217,6 +380,23 @@ __attribute__((visibility("default"))) void vkmr_host_count_lines(const uint8_t*
 {
     const vkmr::LineCount c = which ? vkmr::CountLinesPortable(buf, len) : vkmr::CountLines(buf, len);
     out[0] = c.strings; out[1] = c.words; out[2] = c.bytes; out[3] = c.empties; out[4] = c.too_long ? 1 : 0;
+}
+
+// The indexed two-pass form on one buffer (every line, the last one terminated or not), placed at data[first_word ...):
+// which as above.  Returns the number of strings, or -1 when a buffer was too small; out[0..3] = words, bytes, empties,
+// lines indexed.
+__attribute__((visibility("default"))) int64_t vkmr_host_pack_indexed(const uint8_t* buf, uint64_t len, uint32_t* data, uint64_t first_word,
+                                                                       uint64_t data_capacity_words, vkmr_metadata* meta, uint64_t meta_capacity,
+                                                                       int which, uint64_t* out)
+{
+    if (len >= 0xFFFFFF00ull) return -1;
+    vkmr::LineIndex ix;
+    const vkmr::LineCount c = which ? vkmr::IndexLinesPortable(buf, len, &ix) : vkmr::IndexLines(buf, len, &ix);
+    if (out) { out[0] = c.words; out[1] = c.bytes; out[2] = c.empties; out[3] = ix.count; }
+    if (!ix.ends || first_word + c.words > data_capacity_words || c.strings > meta_capacity) return -1;
+    if (which) vkmr::PackIndexedPortable(buf, len, ix, data, first_word, first_word + c.words, meta);
+    else vkmr::PackIndexed(buf, len, ix, data, first_word, first_word + c.words, meta);
+    return (int64_t)c.strings;
 }
 
 // A prefix split with capacity limits and `final` unset, as the stream processor calls it: out[0..4] = consumed, strings,

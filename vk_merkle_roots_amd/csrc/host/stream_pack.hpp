@@ -34,6 +34,30 @@ PackResult PackLines(const uint8_t* buf, size_t len, bool final, uint32_t* data,
 struct LineCount { uint64_t strings, words, bytes, empties; bool too_long; };
 LineCount CountLines(const uint8_t* buf, size_t len);
 
+// Indexed two-pass form, what the parallel packer runs on each part of a span (Batch::PushLinesParallel): pass 1 records
+// where every line of the part ends and returns what the part will append -- the prefix sums over the parts give every
+// part its place in the batch -- and pass 2 packs from that record without looking for newlines again.
+//   IndexLines   ends[i] = offset of the i-th '\n' of buf[0,len); an unterminated last line ends at len.  len < 2^32 - 64.
+//   PackIndexed  appends the non-empty lines at data[first_word ...) / meta[0 ...); writes nothing at or beyond
+//                data[end_word] (the next part's words are another thread's) and reads nothing beyond buf[len).
+// Same words and metadata as PackLines(final = true) on the same bytes (tests/test_host_tools.py, test_host_fuzz.py).
+struct LineIndex {
+    uint32_t* ends = nullptr;
+    size_t cap = 0, count = 0;
+    LineIndex() = default;
+    LineIndex(const LineIndex&) = delete;
+    LineIndex& operator=(const LineIndex&) = delete;
+    LineIndex(LineIndex&& o) noexcept : ends(o.ends), cap(o.cap), count(o.count) { o.ends = nullptr; o.cap = o.count = 0; }
+    ~LineIndex();
+    void Reserve(size_t lines);   // room for `lines` entries plus the slack the vector form writes past the end; contents are dropped
+};
+LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix);
+void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
+                 vkmr_metadata* meta);
+LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix);
+void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
+                         vkmr_metadata* meta);
+
 // The portable forms (one memchr per line).  PackLines / CountLines use AVX2 forms where the CPU has them (the newline
 // positions of 64 input bytes at a time); these stay as the reference the tests compare them with.
 PackResult PackLinesPortable(const uint8_t* buf, size_t len, bool final, uint32_t* data, uint64_t first_word,

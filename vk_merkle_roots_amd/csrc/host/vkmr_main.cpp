@@ -16,6 +16,7 @@
 #include "cpu_sha256d.hpp"
 #include "hip_sha256d.hpp"
 #include "inputs.hpp"
+#include "timing.hpp"
 #include "util.hpp"
 
 // The input loop (reference run(), src/vkmr/Vkmr.cpp:28-58).
@@ -30,7 +31,10 @@ static int run(vkmr::ISha256D& backend)
         const char* p = nullptr;
         size_t n = 0;
         bool final = false;
-        input.GetBlock(&p, &n, &final);
+        {
+            vkmr::timing::Scope ts(vkmr::timing::READ);
+            input.GetBlock(&p, &n, &final);
+        }
         vkmr::ISha256D::Tally tally;
         refused = !backend.AddLines(p, n, final, &tally);
         // the reference reads one more, empty, string when the stream ends right after a '\n'
@@ -48,6 +52,7 @@ static int run(vkmr::ISha256D& backend)
         // the Merkle proof of one leaf, when asked for (VKMR_PROOF_INDEX; the reference's to-do, README.md:118-120)
         if (auto* hip = dynamic_cast<vkmr::HipSha256D::Instance*>(&backend))
             for (const auto& l : hip->ProofLines()) std::cout << l << std::endl;
+        vkmr::timing::Report(std::cerr);
     }
     return 0;
 }

@@ -357,6 +357,35 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     return VKMR_OK;
 }
 
+// See the header: the first copy and the first launch of a process, taken out of the caller's pipeline.
+vkmr_status vkmr_hip_warm_up(int dev, vkmr_stream s, unsigned what, size_t copy_bytes)
+{
+    VKMR_TRY(hipSetDevice(dev));
+    if (!(what & (VKMR_WARM_KERNELS | VKMR_WARM_COPY))) return VKMR_OK;
+    // one pinned and one device block, of 256 bytes at least: metadata {word 0, 4 bytes} at 0, the string's word at 64, its digest at 128
+    const size_t bytes = (what & VKMR_WARM_COPY) && copy_bytes > 256 ? copy_bytes : 256;
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) {
+        memset(h, 0, 256);
+        static_cast<uint32_t*>(h)[1] = 4u;
+        if (what & VKMR_WARM_COPY) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, S(s));
+        else e = hipMemsetAsync(d, 0, 256, S(s));
+    }
+    if (e == hipSuccess && (what & VKMR_WARM_KERNELS)) {
+        char* base = static_cast<char*>(d);
+        hipLaunchKernelGGL((VKMR_MAP_STAGED_KERNEL), dim3(1), dim3(512), 0, S(s), reinterpret_cast<const uint32_t*>(base + 64), (uint64_t)1,
+                           reinterpret_cast<const vkmr_metadata*>(base), 1u, reinterpret_cast<Node*>(base + 128), 1024u);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(S(s));
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    VKMR_TRY(e);
+    return VKMR_OK;
+}
+
 #define VKMR_STR2(x) #x
 #define VKMR_STR(x) VKMR_STR2(x)
 const char* vkmr_hip_kernel_info(void)
