@@ -249,6 +249,12 @@ def test_parallel_packer_in_the_pipeline_under_tsan(native, golden, tmp_path):
     assert b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:].decode()
     m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
     assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])
+    # the same stream through a pipe: blocks of whole lines come from Input's reading thread (three buffers in turn, the
+    # unfinished last line of one block carried into the next) while this thread and the pool pack the block before
+    r = subprocess.run([exe, "hip:0"], input=path.read_bytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:].decode()
+    m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
+    assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])
 
 
 def fold_proof(lines):

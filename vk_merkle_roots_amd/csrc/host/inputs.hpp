@@ -4,10 +4,13 @@
 // src/vkmr/Inputs.cpp:52-101): '\n' or end of file ends a line, '\r' is kept, Has() is
 // "not at end of file yet" -- so a stream that ends in '\n' yields one final empty
 // string, which the caller skips with a warning (src/vkmr/Vkmr.cpp:40-43).  The
-// reference reads with one fgetc + append per byte; this reader pulls 1 MiB blocks
-// with fread and splits with memchr.
+// reference reads with one fgetc + append per byte; this reader maps a regular file, and
+// takes anything else (the reference's own usage is `rndm ... | vkmr`, README.md:40) in
+// blocks of 8 MiB and more with read(2) -- on a thread of its own once the bulk form is in
+// use, so that the next block arrives while the caller packs this one.
 #pragma once
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -39,7 +42,9 @@ public:
 
 private:
     bool Fill();
-    size_t ReadSome(char* dst, size_t n);   // fread, or a copy out of the mapping
+    size_t ReadSome(char* dst, size_t n);   // read(2) (whatever is there, at least one byte unless the stream has ended), or a copy out of the mapping
+    struct Reader;                           // the reading thread of the bulk form and the blocks it shares with the caller
+    std::shared_ptr<Reader> m_reader;
 
     FILE* m_fp;
     bool m_owner, m_eof;
