@@ -99,7 +99,8 @@ Input::Input(FILE* fp, bool owner)
         }
     }
 #ifdef F_SETPIPE_SZ
-    // a pipe of 1 MiB instead of 64 KiB: sixteen times fewer hand-overs between the writer and this process
+    // a pipe of 1 MiB instead of 64 KiB: fewer hand-overs between the writer and this process (365-430 ms instead of 400-450 for
+    // 2.1 GB from `cat`, whose own limit is 350: profiles/r03_frontend_pipe.txt)
     if (fp && !m_map && fstat(fileno(fp), &st) == 0 && S_ISFIFO(st.st_mode)) (void)fcntl(fileno(fp), F_SETPIPE_SZ, 1 << 20);
 #endif
 }
