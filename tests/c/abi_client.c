@@ -49,6 +49,7 @@ int main(int argc, char** argv)
     vkmr_event done = NULL;
     void *d_data = NULL, *d_meta = NULL, *d_slice = NULL, *d_scratch = NULL, *d_root = NULL;
     CHECK(vkmr_hip_stream_create(0, &s));
+    CHECK(vkmr_hip_warm_up(0, s, VKMR_WARM_KERNELS | VKMR_WARM_COPY, (size_t)1 << 20));   /* the reference's pipeline creation at start-up */
     CHECK(vkmr_hip_event_create(0, &done));
     CHECK(vkmr_hip_device_alloc(0, (words ? words : 1) * 4, &d_data));
     CHECK(vkmr_hip_device_alloc(0, count * sizeof(vkmr_metadata), &d_meta));

@@ -24,6 +24,17 @@ def batch_of(strings):
 
 # ---- map ------------------------------------------------------------------------
 
+def test_warm_up_leaves_no_trace(gpu, oracle):
+    """vkmr_hip_warm_up (kernels, copy engine, both, neither; small and large copies; the device's stream and a new one)
+    returns VKMR_OK, and launches after it give what they give without it."""
+    import vk_merkle_roots_amd as vk
+    b = vk.rndm_packed(5, 3000, 127)
+    want = [oracle.hex(r) for r in gpu.leaf_digests(b)]
+    other = gpu.new_stream()
+    for kernels, copy_bytes, stream in ((True, 1 << 20, None), (True, 0, None), (False, 256, None), (False, 0, None), (True, 40 << 20, other), (True, 1, other)):
+        gpu.warm_up(kernels=kernels, copy_bytes=copy_bytes, stream=stream)
+        assert [oracle.hex(r) for r in gpu.leaf_digests(b)] == want
+
 def test_map_golden_leaves(gpu, oracle, golden):
     msgs = [golden_pattern(v["len"], v["salt"]) for v in golden["leaves"]]
     got = gpu.leaf_digests(batch_of(msgs))

@@ -169,6 +169,12 @@ class HipDevice:
         check(self.lib.vkmr_hip_stream_create(self.index, C.byref(s)), "vkmr_hip_stream_create")
         return s.value
 
+    def warm_up(self, kernels=True, copy_bytes=1 << 20, stream=None):
+        """vkmr_hip_warm_up: the kernels loaded onto the device, the copy engine up -- what a caller does at start-up
+        instead of inside its first copy and first launch (the reference builds its pipelines then: Devices.cpp:225-280)."""
+        what = (1 if kernels else 0) | (2 if copy_bytes else 0)
+        check(self.lib.vkmr_hip_warm_up(self.index, stream or self.stream, what, copy_bytes or 0), "vkmr_hip_warm_up")
+
     def new_event(self):
         e = C.c_void_p()
         check(self.lib.vkmr_hip_event_create(self.index, C.byref(e)), "vkmr_hip_event_create")
