@@ -191,6 +191,41 @@ def pipeline_rate(vk, batch, bstr, slice_log2, device=0, runs=3):
             "runs_ms": [t * 1e3 for t in times]}
 
 
+def from_file_rate(seed, count, maxlen, device, runs=3, timeout_s=300):
+    """The reference's own measurement shape (src/vkmr/Vkmr.cpp:28-58: newline-separated strings on stdin, one stopwatch
+    around reading, hashing and the tree): the product's `vkmr hip:<n>` fed the SAME stream as the timed steps from a
+    file, its own "... in <ms>" line and the process wall clock.  Host packer + PCIe + kernels; reported beside `value`,
+    never as it."""
+    import tempfile
+    rndm = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "rndm")
+    vkmr = os.path.join(ROOT, "vk_merkle_roots_amd", "bin", "vkmr")
+    if not (os.path.exists(rndm) and os.path.exists(vkmr)):
+        return {"error": "vk_merkle_roots_amd/bin/{rndm,vkmr} missing: run `python -m vk_merkle_roots_amd.build`"}
+    with tempfile.NamedTemporaryFile(prefix="vkmr_stream_", suffix=".txt") as tmp:
+        subprocess.run([rndm, str(seed), str(count), str(maxlen)], stdout=tmp, stderr=subprocess.DEVNULL, check=True, timeout=timeout_s)
+        tmp.flush()
+        nbytes = os.path.getsize(tmp.name)
+        printed, walls, root, items = [], [], None, None
+        for _ in range(runs + 1):   # the first run also warms the page cache's mapping of the file
+            with open(tmp.name, "rb") as f:
+                t0 = time.perf_counter()
+                r = subprocess.run([vkmr, f"hip:{device}"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
+                walls.append(time.perf_counter() - t0)
+            line = [l for l in r.stdout.decode().splitlines() if "computed root" in l]
+            if r.returncode != 0 or not line:
+                return {"error": f"vkmr hip:{device} failed (rc {r.returncode})"}
+            printed.append(float(line[-1].rsplit(" in ", 1)[1]))
+            root = line[-1].split("=> ")[1].split(" in ")[0]
+            items = int(line[-1].split("(of ")[1].split(" item")[0])
+    ms = float(np.median(printed[1:]))
+    return {"workload": f"rndm {seed} {count} {maxlen} in a file on stdin ({nbytes} bytes)", "printed_ms": ms, "printed_ms_runs": printed,
+            "process_wall_s": float(np.median(walls[1:])), "leaf_hashes_per_s": count / (ms / 1e3), "text_GBps": nbytes / (ms / 1e3) / 1e9,
+            "items": items, "root_hex": root,
+            "what": "`vkmr hip:<n> < file`: mapped file -> 16-thread indexed packer -> pinned batches -> H2D on the copy stream, map kernel behind "
+                    "it -> slices of 2^23 reduced as they fill -> combine; the program's own stopwatch (it starts, like the reference's, after "
+                    "the backend is constructed)"}
+
+
 def two_stream_rate(dev, vk, d_batch, bstr, n, slice_height, steps=8):
     """The same work with the map on one stream and the reduction on another, as the stream processor runs them
     (csrc/host/hip_sha256d.cpp: map_stream / reduce_stream per device): step k+1's map fills the chip while step k's
@@ -696,6 +731,11 @@ def main():
                                               "what": "libvkmr_pipeline.so: strings staged in the C++ stream processor's pinned batches, then its own "
                                                       "schedule -- per batch H2D on the copy stream and the map kernel behind it, slices of 2^23 to "
                                                       "Reductions as they fill, combine on the device (Mappings::Map / Reductions of `vkmr hip:0`)"}
+        if world == 1 and not a.no_pipeline and not a.levels_variant:
+            ff = from_file_rate(a.seed, n, a.maxlen, local_rank)
+            if "root_hex" in ff:
+                ff["root_matches"] = ff.pop("root_hex") == root_hex and ff["items"] == n
+            out["from_file_on_stdin"] = ff
         if world == 1 and not a.no_long_strings:
             out["long_strings"] = long_strings_rate(dev, vk, a.seed)
         # ---- the bound the path sits under: VALU issue at the clock each kernel holds -------------------------------

@@ -358,6 +358,15 @@ bool HipSha256D::Instance::MapCurrent()
         pd.prefetched = true;
         pd.batches->Prefetch(m_cfg.max_inflight);
     }
+    if (m_devs.size() > 1 && !m_draining && m_batch.Words() * 4 >= pd.batches->DataBytes() / 2) {
+        // several devices: the slice after this one goes to the next device of the deal -- its batches are pinned while
+        // this slice fills, not when its first strings arrive (pinning stalls the packer: profiles/r03_frontend_setup_orders.txt)
+        PerDevice& next = m_devs[((size_t)(&pd - m_devs.data()) + 1) % m_devs.size()];
+        if (!next.prefetched) {
+            next.prefetched = true;
+            next.batches->Prefetch(m_cfg.max_inflight + 1);
+        }
+    }
     return m_mappings->Map(std::move(m_batch), slice.Sub(), pd.map_stream, pd.copy_stream) == VKMR_OK;
 }
 
