@@ -4,7 +4,9 @@
 // they replaced (CountLines / PackLines).
 //   g++ -O2 -std=c++17 -pthread -I vk_merkle_roots_amd/csrc/host -I include -o tools/pack_bench tools/pack_bench.cpp vk_merkle_roots_amd/csrc/host/stream_pack.cpp
 //   tools/pack_bench file [threads=16] [span MiB=32] [resident=0]     resident=1: the file is read into memory first (no page faults
-//                                                                      of the mapping inside the timed passes)
+//                                                                      of the mapping inside the timed passes); 2: mapped, every span
+//                                                                      populated with madvise(MADV_POPULATE_READ) before it is indexed;
+//                                                                      3: the same on a helper thread, one span ahead
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -14,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "fork_join.hpp"
@@ -31,7 +35,8 @@ int main(int argc, char** argv)
     struct stat st;
     if (fd < 0 || fstat(fd, &st) != 0) return 1;
     const size_t len = (size_t)st.st_size;
-    const bool resident = argc > 4 && atoi(argv[4]) != 0;
+    const int mode = argc > 4 ? atoi(argv[4]) : 0;
+    const bool resident = mode == 1;
     std::vector<uint8_t> copy;
     if (resident) {
         copy.resize(len);
@@ -53,11 +58,31 @@ int main(int argc, char** argv)
             if (b == MAP_FAILED) return 1;
             if (!resident) madvise(const_cast<uint8_t*>(b), len, MADV_SEQUENTIAL);
             std::vector<LineIndex> index(T);
-            double t1 = 0, t2 = 0;
+            double t1 = 0, t2 = 0, t3 = 0;
             size_t lines = 0;
             const double t0 = now();
+            std::thread ahead;
             for (size_t at = 0; at < len;) {
                 size_t usable = len - at < span ? len - at : span;
+#ifdef MADV_POPULATE_READ
+                if (mode == 2) {
+                    const double p0 = now();
+                    const size_t lo_pg = at & ~(size_t)4095;
+                    madvise(const_cast<uint8_t*>(b) + lo_pg, at + usable - lo_pg, MADV_POPULATE_READ);
+                    t3 += now() - p0;
+                }
+                if (mode == 3) {
+                    const double p0 = now();
+                    if (ahead.joinable()) ahead.join();
+                    else { const size_t lo_pg = at & ~(size_t)4095; madvise(const_cast<uint8_t*>(b) + lo_pg, at + usable - lo_pg, MADV_POPULATE_READ); }
+                    t3 += now() - p0;
+                    const size_t nxt = (at + usable) & ~(size_t)4095;
+                    if (nxt < len) {
+                        const size_t n2 = len - nxt < span + 8192 ? len - nxt : span + 8192;
+                        ahead = std::thread([b, nxt, n2] { madvise(const_cast<uint8_t*>(b) + nxt, n2, MADV_POPULATE_READ); });
+                    }
+                }
+#endif
                 if (at + usable < len) {
                     const void* nl = memrchr(b + at, '\n', usable);
                     if (nl) usable = (size_t)(static_cast<const uint8_t*>(nl) - (b + at)) + 1;
@@ -91,10 +116,11 @@ int main(int argc, char** argv)
                 lines += n;
                 at += usable;
             }
+            if (ahead.joinable()) ahead.join();
             const double total = now() - t0;
-            printf("%s, %s, %u threads, spans of %zu MiB: %.1f ms = %.1f GB/s (%zu lines; pass 1 %.1f ms, pass 2 %.1f ms; %.2f + %.2f ns per line and thread)\n",
-                   resident ? "resident" : "mapped", form == 0 ? "index + pack-indexed" : "count + pack (per-line walk)", T, span >> 20, total * 1e3, (double)len / total / 1e9, lines, t1 * 1e3, t2 * 1e3,
-                   t1 / (double)lines * 1e9 * T, t2 / (double)lines * 1e9 * T);
+            printf("%s, %s, %u threads, spans of %zu MiB: %.1f ms = %.1f GB/s (%zu lines; pass 1 %.1f ms, pass 2 %.1f ms; %.2f + %.2f ns per line and thread)%s\n",
+                   resident ? "resident" : mode == 2 ? "mapped+populate" : mode == 3 ? "mapped+populate ahead" : "mapped", form == 0 ? "index + pack-indexed" : "count + pack (per-line walk)", T, span >> 20, total * 1e3, (double)len / total / 1e9, lines, t1 * 1e3, t2 * 1e3,
+                   t1 / (double)lines * 1e9 * T, t2 / (double)lines * 1e9 * T, mode >= 2 ? (" populate wait " + std::to_string(t3 * 1e3) + " ms").c_str() : "");
             if (!resident) munmap(const_cast<uint8_t*>(b), len);
         }
     }
