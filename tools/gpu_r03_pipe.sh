@@ -4,10 +4,8 @@ mkdir -p gpurun_out/r03
 vk_merkle_roots_amd/bin/rndm 42 33554432 127 > /tmp/g25.txt 2>/dev/null
 vk_merkle_roots_amd/bin/vkmr hip:0 < /tmp/g25.txt > /dev/null 2>&1
 for round in 1 2; do
-for kb in 0 64 256 1024; do
-  echo "# cat file | VKMR_PIPE_KB=$kb vkmr hip:0"
-  cat /tmp/g25.txt | VKMR_PIPE_KB=$kb VKMR_TIMING=1 vk_merkle_roots_amd/bin/vkmr hip:0 2>&1 | grep -E "computed|read \(|pass 1|pass 2"
-done
+echo "# cat file | vkmr hip:0"
+cat /tmp/g25.txt | VKMR_TIMING=1 vk_merkle_roots_amd/bin/vkmr hip:0 2>&1 | grep -E "computed|read \(|pass 1|pass 2"
 echo "# dd bs=1M | vkmr (pipe 1024)"
 dd if=/tmp/g25.txt bs=1M 2>/dev/null | VKMR_TIMING=1 vk_merkle_roots_amd/bin/vkmr hip:0 2>&1 | grep -E "computed|read \("
 echo "# rndm | vkmr"
