@@ -343,3 +343,22 @@ def test_packed_pipeline_entry_point_on_the_gpu(native, golden):
         rc = L.vkmr_host_pipeline_packed(0, b.data.ctypes.data, b.words, b.meta.ctypes.data, b.count, per_batch, slice_log2, hexbuf, C.byref(secs))
         assert rc == 0 and hexbuf.value.decode() == want, (per_batch, slice_log2, rc, hexbuf.value)
         assert 0 < secs.value < 5
+
+
+@pytest.mark.gpu
+def test_text_pipeline_entry_point_on_the_gpu(native, golden):
+    """vkmr_host_pipeline_text (libvkmr_pipeline.so): the reference's run() as one call on text in memory -- the parallel
+    packer, pinned batches, copy and map streams, reductions, combine, as `vkmr hip:0 < file` runs them -- against the
+    golden root of rndm 42 2^20 127 (printed by the reference's CPU path), whole and in spans of 1 and 5 MiB."""
+    import ctypes as C
+    from vk_merkle_roots_amd.build import PIPELINE_LIB
+    L = C.CDLL(PIPELINE_LIB)
+    L.vkmr_host_pipeline_text.restype = C.c_int
+    L.vkmr_host_pipeline_text.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    text = stream_of(native, s)
+    for span in (0, 1 << 20, 5 << 20):
+        hexbuf, items, nbytes, secs = C.create_string_buffer(65), C.c_uint64(), C.c_uint64(), C.c_double()
+        rc = L.vkmr_host_pipeline_text(0, text, len(text), span, hexbuf, C.byref(items), C.byref(nbytes), C.byref(secs))
+        assert (rc, hexbuf.value.decode(), items.value, nbytes.value) == (0, s["root"], s["items"], s["bytes"]), span
+        assert 0 < secs.value < 5

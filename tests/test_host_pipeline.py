@@ -323,8 +323,21 @@ for seed, n, maxlen, per_batch, slice_log2, dev in ((3, 5000, 127, 700, 10, 0), 
     hexbuf = C.create_string_buffer(65); secs = C.c_double()
     rc = L.vkmr_host_pipeline_packed(dev, b.data.ctypes.data, b.words, b.meta.ctypes.data, b.count, per_batch, slice_log2, hexbuf, C.byref(secs))
     res.append((seed, n, maxlen, rc, hexbuf.value.decode()))
-print(json.dumps(res))
-''' % (ROOT, lib)
+L.vkmr_host_pipeline_text.restype = C.c_int
+L.vkmr_host_pipeline_text.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+text = []
+import subprocess
+for seed, n, maxlen, span, dev in ((11, 40000, 127, 0, 0), (12, 40000, 127, 1 << 20, -1), (13, 300, 3000, 4096, 0), (14, 3, 5, 0, 0)):
+    t = subprocess.run([%r, str(seed), str(n), str(maxlen)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    for variant, body in (("as written", t), ("no final newline, empty lines, a CR", b"\n\n" + t[:-1].replace(b"\n", b"\r\n\n", 1))):
+        hexbuf = C.create_string_buffer(65); items = C.c_uint64(); nbytes = C.c_uint64(); secs = C.c_double()
+        rc = L.vkmr_host_pipeline_text(dev, body, len(body), span, hexbuf, C.byref(items), C.byref(nbytes), C.byref(secs))
+        text.append((seed, n, maxlen, variant, rc, hexbuf.value.decode(), items.value, nbytes.value))
+hexbuf = C.create_string_buffer(65); items = C.c_uint64(7); nbytes = C.c_uint64(7)
+rc = L.vkmr_host_pipeline_text(0, b"\n\n\n", 3, 0, hexbuf, C.byref(items), C.byref(nbytes), None)
+text.append((0, 0, 0, "only empty lines", rc, hexbuf.value.decode(), items.value, nbytes.value))
+print(json.dumps([res, text]))
+''' % (ROOT, lib, os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm"))
     env = {k: v for k, v in os.environ.items() if not k.startswith("VKMR_") and k != "LD_PRELOAD"}
     env.update(VKMR_FAKE_DEVICES="3", VKMR_BATCH_MAX_MB="0")
     r = subprocess.run([os.sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
@@ -332,7 +345,18 @@ print(json.dumps(res))
     import json
     import vk_merkle_roots_amd as vk
     from vk_merkle_roots_amd.engine import digest_hex
-    for seed, n, maxlen, rc, root in json.loads(r.stdout.decode().splitlines()[-1]):
+    packed, text = json.loads(r.stdout.decode().splitlines()[-1])
+    for seed, n, maxlen, rc, root in packed:
         b = vk.rndm_packed(seed, n, maxlen)
         want = digest_hex(oracle.root(oracle.leaves_packed(b.data, b.meta)))
         assert rc == 0 and root == want, (seed, n, maxlen, rc, root, want)
+    # vkmr_host_pipeline_text: the reference's run() as one call on text in memory -- same line rules as stdin
+    tool = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    for seed, n, maxlen, variant, rc, root, items, nbytes in text:
+        if variant == "only empty lines":
+            assert (rc, root, items, nbytes) == (0, "", 0, 0)
+            continue
+        t = subprocess.run([tool, str(seed), str(n), str(maxlen)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        body = t if variant == "as written" else b"\n\n" + t[:-1].replace(b"\n", b"\r\n\n", 1)
+        want, cnt, nb = oracle.root_of_stream(body)
+        assert (rc, root, items, nbytes) == (0, want, cnt, nb), (seed, n, maxlen, variant, rc, root, want)
