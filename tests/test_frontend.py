@@ -356,7 +356,7 @@ def test_text_pipeline_entry_point_on_the_gpu(native, golden):
     L.vkmr_host_pipeline_text.restype = C.c_int
     L.vkmr_host_pipeline_text.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     s = golden["streams"]["G3_rndm_42_1048576_127"]
-    text = stream_of(native, s)
+    text = golden_stream(native, s)
     for span in (0, 1 << 20, 5 << 20):
         hexbuf, items, nbytes, secs = C.create_string_buffer(65), C.c_uint64(), C.c_uint64(), C.c_double()
         rc = L.vkmr_host_pipeline_text(0, text, len(text), span, hexbuf, C.byref(items), C.byref(nbytes), C.byref(secs))
