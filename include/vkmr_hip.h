@@ -161,6 +161,20 @@ VKMR_API vkmr_status vkmr_hip_reduce_async(int dev, vkmr_stream s,
 VKMR_API size_t vkmr_hip_reduce_scratch_bytes(uint64_t count);
 
 /*
+ * METADATA FROM SIZES.  The strings of a batch lie back to back (string i + 1 starts on the word after string i:
+ * Batch::Push, src/vkmr/Batches.cpp:64-121), so entry i is {first_word + sum over j < i of ceil(size[j] / 4), size[i]}:
+ * what the reference's host code computes while it appends (WordCount, Batches.cpp:182-187).  A caller that feeds the
+ * device over PCIe may send the 16-bit sizes (2 bytes per string instead of 8) and have the entries written in device
+ * memory, where vkmr_hip_map_async reads them.  Every size must be below 65 536 (send the entries themselves otherwise).
+ *   sizes_dev    count sizes, 16-byte aligned
+ *   scratch_dev  vkmr_hip_sizes_scratch_bytes(count) bytes
+ *   meta_dev     count entries, 16-byte aligned, written
+ */
+VKMR_API vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream s, const uint16_t* sizes_dev, uint32_t count,
+                                                        uint32_t first_word, void* scratch_dev, vkmr_metadata* meta_dev);
+VKMR_API size_t vkmr_hip_sizes_scratch_bytes(uint32_t count);
+
+/*
  * REDUCE, several slices at once: `nslices` consecutive slices of `capacity` digests
  * each (a power of two), the last holding `count_last` <= capacity, all reduced
  * through `height` levels by the same launches; roots_dev[k] receives slice k's

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -183,6 +184,31 @@ vkmr_status vkmr_hip_memcpy_d2h_async(int, vkmr_stream, void* dst, const void* s
     return VKMR_OK;
 }
 
+// VKMR_FAKE_COUNT_FORMS=1: at exit, how many map launches found their entries written by vkmr_hip_metadata_from_sizes_async
+// (the batch crossed as 16-bit sizes) and how many did not (it crossed as entries)
+static std::atomic<unsigned long> g_from_sizes{0}, g_maps{0};
+static const vkmr_metadata* g_last_expanded = nullptr;
+static void report_forms()
+{
+    fprintf(stderr, "fake: batches described by sizes %lu, by entries %lu\n", g_from_sizes.load(), g_maps.load() - g_from_sizes.load());
+}
+size_t vkmr_hip_sizes_scratch_bytes(uint32_t count) { return ((size_t)count / 4096u + 2u) * 4u; }
+vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream, const uint16_t* sizes, uint32_t count, uint32_t first_word, void* scratch,
+                                               vkmr_metadata* meta)
+{
+    if (!dev_ok(dev) || (count && (!sizes || !scratch || !meta))) return fail(VKMR_ERR_INVALID, "metadata_from_sizes");
+    if (count && (room_at(sizes) < (size_t)count * 2 || room_at(meta) < (size_t)count * sizeof(vkmr_metadata) || room_at(scratch) < vkmr_hip_sizes_scratch_bytes(count)))
+        return fail(VKMR_ERR_INVALID, "metadata_from_sizes: outside device memory");
+    uint32_t w = first_word;
+    for (uint32_t i = 0; i < count; ++i) {
+        meta[i].start = w;
+        meta[i].size = sizes[i];
+        w += (sizes[i] + 3u) / 4u;
+    }
+    g_last_expanded = meta;
+    return VKMR_OK;
+}
+
 vkmr_status vkmr_hip_warm_up(int dev, vkmr_stream, unsigned, size_t) { return dev_ok(dev) ? VKMR_OK : fail(VKMR_ERR_INVALID, "warm_up"); }
 
 vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)
@@ -254,6 +280,12 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream, const uint32_t* data, uint6
     if (room_at(meta) < (size_t)count * 8 || room_at(out) < (size_t)count * 32 || (data_words && room_at(data) < data_words * 4))
         return fail(VKMR_ERR_INVALID, "map: a buffer is not (large enough) device memory");
     static const bool no_hash = env_long("VKMR_FAKE_NO_HASH", 0) != 0;
+    static const bool count_forms = env_long("VKMR_FAKE_COUNT_FORMS", 0) != 0 && atexit(report_forms) == 0;
+    if (count_forms) {
+        ++g_maps;
+        if (g_last_expanded == meta) ++g_from_sizes;
+        g_last_expanded = nullptr;
+    }
     for (uint32_t i = 0; i < count && !no_hash; ++i) {
         uint64_t size = meta[i].size;
         const uint64_t avail = meta[i].start < data_words ? (data_words - meta[i].start) * 4 : 0;   // same cut as the kernel

@@ -24,6 +24,32 @@ def batch_of(strings):
 
 # ---- map ------------------------------------------------------------------------
 
+def test_metadata_from_sizes(gpu):
+    """vkmr_hip_metadata_from_sizes_async: entry i = {first_word + sum over j < i of ceil(size[j] / 4), size[j]} -- what
+    Batch::Push computes on the host (reference src/vkmr/Batches.cpp:64-121) -- against numpy, for counts around the
+    kernels' 16-per-lane and 4096-per-workgroup edges, a batch of 2^20 + 3 strings, zero sizes and the largest size."""
+    import vk_merkle_roots_amd as vk
+    rng = np.random.default_rng(77)
+    for count, first_word, hi in ((1, 0, 200), (15, 7, 200), (16, 0, 200), (17, 3, 200), (4095, 0, 128), (4096, 1, 128), (4097, 0, 128),
+                                  (100000, 12345, 65535), ((1 << 20) + 3, 0, 128), (300000, 0, 1)):
+        sizes = rng.integers(0, hi + 1, size=count, dtype=np.uint32).astype(np.uint16)
+        if hi == 65535:
+            sizes[[0, count // 2, count - 1]] = 65535
+        d_sizes = gpu.upload(sizes)
+        d_meta = gpu.alloc(8 * count + 16)
+        d_scratch = gpu.alloc(gpu.lib.vkmr_hip_sizes_scratch_bytes(count))
+        vk.check(gpu.lib.vkmr_hip_metadata_from_sizes_async(gpu.index, gpu.stream, d_sizes.ptr, count, first_word, d_scratch.ptr, d_meta.ptr), "from_sizes")
+        got = gpu.download(d_meta, 8 * count).reshape(-1, 2)
+        words = (sizes.astype(np.uint64) + 3) // 4
+        starts = first_word + np.concatenate(([0], np.cumsum(words)[:-1]))
+        assert np.array_equal(got[:, 1], sizes.astype(np.uint32)), count
+        assert np.array_equal(got[:, 0].astype(np.uint64), starts.astype(np.uint64)), count
+        for b in (d_sizes, d_meta, d_scratch):
+            b.free()
+    assert gpu.lib.vkmr_hip_metadata_from_sizes_async(gpu.index, gpu.stream, None, 0, 0, None, None) == 0      # nothing to do
+    assert gpu.lib.vkmr_hip_metadata_from_sizes_async(gpu.index, gpu.stream, None, 5, 0, None, None) < 0       # null pointers are refused
+
+
 def test_warm_up_leaves_no_trace(gpu, oracle):
     """vkmr_hip_warm_up (kernels, copy engine, both, neither; small and large copies; the device's stream and a new one)
     returns VKMR_OK, and launches after it give what they give without it."""

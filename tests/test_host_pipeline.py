@@ -188,6 +188,35 @@ def test_hip_all_deals_one_slice_per_device_when_the_input_size_is_known(fake_vk
     assert any(l.startswith("Slices of 2^23 digests") for l in out) and [m for m in (LINE.match(l) for l in out) if m][-1].group("root") == want
 
 
+def test_batches_cross_as_sizes_or_as_entries(fake_vkmr, native, oracle):
+    """A batch whose strings are all shorter than 65 536 bytes is described to the device by 16-bit sizes
+    (vkmr_hip_metadata_from_sizes_async writes the entries there); one string of 65 535 bytes or more and the batch goes
+    with its 8-byte entries, as the reference sends them.  Both give the oracle's root, at the boundary sizes, with the
+    long string first, last, alone in its batch, and with VKMR_SEND_METADATA=1 forcing the entries throughout; the fake
+    ABI counts which form each batch took."""
+    tool = os.path.join(os.path.dirname(native.HIP_LIB), "bin", "rndm")
+    short = subprocess.run([tool, "9", "3000", "200"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    cases = {"short only": short,
+             "65534 bytes": b"a" * 65534 + b"\n" + short,
+             "65535 bytes": short + b"b" * 65535 + b"\n",
+             "65536 bytes in the middle": short + b"c" * 65536 + b"\n" + short,
+             "70000 bytes alone": b"d" * 70000 + b"\n"}
+    for name, stream in cases.items():
+        want, cnt, nb = oracle.root_of_stream(stream)
+        for knobs in ({}, {"VKMR_SEND_METADATA": 1}, {"VKMR_BATCH_BYTES": 262144, "VKMR_BATCH_MAX_MB": 0, "VKMR_SLICE_LOG2": 9}):
+            r, out, m = run(fake_vkmr, "hip:0", stream, VKMR_FAKE_COUNT_FORMS=1, **knobs)
+            assert m and (int(m["items"]), m["root"]) == (cnt, want), (name, knobs, r.stderr[-300:])
+            forms = [l for l in r.stderr.decode().splitlines() if l.startswith("fake: batches described by")]
+            assert forms, r.stderr[-300:]
+            by_sizes, by_entries = (int(x) for x in re.findall(r"(\d+)", forms[-1])[:2])
+            if knobs.get("VKMR_SEND_METADATA"):
+                assert by_sizes == 0 and by_entries > 0, (name, knobs, forms)
+            elif name in ("short only", "65534 bytes"):
+                assert by_entries == 0 and by_sizes > 0, (name, knobs, forms)
+            else:
+                assert by_entries > 0, (name, knobs, forms)
+
+
 @pytest.mark.parametrize("which", range(1, 40, 3))
 def test_a_failing_event_never_yields_a_wrong_root(fake_vkmr, native, golden, which):
     """a mapping or reduction whose event reports a device error must not contribute a zero-filled or

@@ -20,10 +20,12 @@ Batch& Batch::operator=(Batch&& o) noexcept
         Release();
         m_owner = o.m_owner; m_dev = o.m_dev;
         m_data = o.m_data; m_meta = o.m_meta; m_ddata = o.m_ddata; m_dmeta = o.m_dmeta;
+        m_sizes = o.m_sizes; m_dsizes = o.m_dsizes; m_dscratch = o.m_dscratch; m_longest = o.m_longest;
         m_cap_words = o.m_cap_words; m_cap_count = o.m_cap_count;
         m_count = o.m_count; m_words = o.m_words; m_bytes = o.m_bytes; m_number = o.m_number;
         o.m_owner = nullptr; o.m_data = nullptr; o.m_meta = nullptr; o.m_ddata = nullptr; o.m_dmeta = nullptr;
-        o.m_count = o.m_words = o.m_bytes = 0;
+        o.m_sizes = nullptr; o.m_dsizes = nullptr; o.m_dscratch = nullptr;
+        o.m_count = o.m_words = o.m_bytes = o.m_longest = 0;
     }
     return *this;
 }
@@ -33,7 +35,20 @@ void Batch::Release()
     if (m_owner && m_data) m_owner->Recycle(*this);
     m_owner = nullptr;
     m_data = nullptr; m_meta = nullptr; m_ddata = nullptr; m_dmeta = nullptr;
-    m_count = m_words = m_bytes = 0;
+    m_sizes = nullptr; m_dsizes = nullptr; m_dscratch = nullptr;
+    m_count = m_words = m_bytes = m_longest = 0;
+}
+
+void Batch::NoteSizes(size_t first, size_t count)
+{
+    if (!m_sizes) return;
+    size_t longest = m_longest;
+    for (size_t i = first; i < first + count; ++i) {
+        const uint32_t n = m_meta[i].size;
+        m_sizes[i] = (uint16_t)(n < 0xFFFFu ? n : 0xFFFFu);
+        longest = n > longest ? n : longest;
+    }
+    m_longest = longest;
 }
 
 bool Batch::Push(const char* p, size_t n)
@@ -48,6 +63,7 @@ bool Batch::Push(const char* p, size_t n)
         m_data[m_words + nw - 1] = 0u;   // pad bytes of the last word are zero (the kernel masks them anyway)
         std::memcpy(m_data + m_words, p, n);
     }
+    NoteSizes(m_count, 1);
     m_words += nw;
     m_bytes += n;
     m_count += 1;
@@ -77,6 +93,7 @@ size_t Batch::PushPacked(const uint32_t* data, const vkmr_metadata* meta, size_t
         m_meta[m_count + i].size = meta[i].size;
         bytes += meta[i].size;
     }
+    NoteSizes(m_count, take);
     m_words += nw;
     m_bytes += bytes;
     m_count += take;
@@ -101,6 +118,7 @@ PackResult Batch::PushLines(const char* buf, size_t len, bool final, size_t max_
     size_t room = m_cap_count - m_count;
     if (room > max_strings) room = max_strings;
     r = PackLines(reinterpret_cast<const uint8_t*>(buf), len, final, m_data, m_words, m_cap_words, m_meta + m_count, room);
+    NoteSizes(m_count, r.strings);
     m_count += r.strings;
     m_words += r.words;
     m_bytes += r.bytes;
@@ -187,12 +205,14 @@ PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, siz
     {
         timing::Scope ts(timing::PACK);
         pool.Run((unsigned)k, [&](unsigned t) {
-            PackIndexed(b + parts[t].lo, parts[t].hi - parts[t].lo, index[t], m_data, w0[t], w0[t] + parts[t].c.words, m_meta + c0[t]);
+            PackIndexed(b + parts[t].lo, parts[t].hi - parts[t].lo, index[t], m_data, w0[t], w0[t] + parts[t].c.words, m_meta + c0[t],
+                        m_sizes ? m_sizes + c0[t] : nullptr);
         });
     }
     for (size_t t = 0; t < k; ++t) {
         r.bytes += parts[t].c.bytes;
         r.empties += parts[t].c.empties;
+        if (parts[t].c.longest > m_longest) m_longest = parts[t].c.longest;
     }
     r.consumed = parts[k - 1].hi;
     r.strings = strings;
@@ -223,8 +243,11 @@ void Batches::Free(Buffers& b)
 {
     vkmr_hip_host_free(b.data);
     vkmr_hip_host_free(b.meta);
+    vkmr_hip_host_free(b.sizes);
     vkmr_hip_device_free(m_dev, b.ddata);
     vkmr_hip_device_free(m_dev, b.dmeta);
+    vkmr_hip_device_free(m_dev, b.dsizes);
+    vkmr_hip_device_free(m_dev, b.dscratch);
 }
 
 Batches::~Batches()
@@ -243,16 +266,21 @@ void Batches::JoinPrefetch()
 
 bool Batches::Allocate(size_t words, size_t count, Buffers* out)
 {
-    void *h1 = nullptr, *h2 = nullptr, *d1 = nullptr, *d2 = nullptr;
+    void *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *d4 = nullptr;
+    const size_t count32 = count > 0xFFFFFFFFull ? 0xFFFFFFFFull : count;
     const bool ok = vkmr_hip_host_alloc(words * 4, &h1) == VKMR_OK && vkmr_hip_host_alloc(count * sizeof(vkmr_metadata), &h2) == VKMR_OK &&
+                    vkmr_hip_host_alloc(count * sizeof(uint16_t), &h3) == VKMR_OK &&
                     vkmr_hip_device_alloc(m_dev, words * 4, &d1) == VKMR_OK &&
-                    vkmr_hip_device_alloc(m_dev, count * sizeof(vkmr_metadata), &d2) == VKMR_OK;
+                    vkmr_hip_device_alloc(m_dev, count * sizeof(vkmr_metadata), &d2) == VKMR_OK &&
+                    vkmr_hip_device_alloc(m_dev, count * sizeof(uint16_t), &d3) == VKMR_OK &&
+                    vkmr_hip_device_alloc(m_dev, vkmr_hip_sizes_scratch_bytes((uint32_t)count32), &d4) == VKMR_OK;
     if (!ok) {   // the caller waits for a mapping to retire and tries again, or reports the failure
-        vkmr_hip_host_free(h1); vkmr_hip_host_free(h2);
-        vkmr_hip_device_free(m_dev, d1); vkmr_hip_device_free(m_dev, d2);
+        vkmr_hip_host_free(h1); vkmr_hip_host_free(h2); vkmr_hip_host_free(h3);
+        vkmr_hip_device_free(m_dev, d1); vkmr_hip_device_free(m_dev, d2); vkmr_hip_device_free(m_dev, d3); vkmr_hip_device_free(m_dev, d4);
         return false;
     }
-    *out = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1), static_cast<vkmr_metadata*>(d2), words, count};
+    *out = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1), static_cast<vkmr_metadata*>(d2), words, count,
+            static_cast<uint16_t*>(h3), static_cast<uint16_t*>(d3), d4};
     return true;
 }
 
@@ -298,7 +326,7 @@ void Batches::Reshape(size_t data_bytes, size_t meta_count)
 Batch Batches::New()
 {
     Batch b;
-    Buffers buf = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    Buffers buf = {nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
     bool have = false;
     {
         std::unique_lock<std::mutex> lock(m_mu);
@@ -316,6 +344,7 @@ Batch Batches::New()
     }
     b.m_owner = this; b.m_dev = m_dev;
     b.m_data = buf.data; b.m_meta = buf.meta; b.m_ddata = buf.ddata; b.m_dmeta = buf.dmeta;
+    b.m_sizes = buf.sizes; b.m_dsizes = buf.dsizes; b.m_dscratch = buf.dscratch;
     b.m_cap_words = buf.words; b.m_cap_count = buf.count;
     b.m_number = m_next++;
     ++m_live;
@@ -324,7 +353,7 @@ Batch Batches::New()
 
 void Batches::Recycle(Batch& b)
 {
-    Buffers buf = {b.m_data, b.m_meta, b.m_ddata, b.m_dmeta, b.m_cap_words, b.m_cap_count};
+    Buffers buf = {b.m_data, b.m_meta, b.m_ddata, b.m_dmeta, b.m_cap_words, b.m_cap_count, b.m_sizes, b.m_dsizes, b.m_dscratch};
     if (buf.words == m_words && buf.count == m_count) {
         std::lock_guard<std::mutex> lock(m_mu);
         m_free.push_back(buf);

@@ -1,5 +1,10 @@
 // batches.hpp -- packed input batches.
 //
+// Invariant: the strings of a batch lie back to back -- string i + 1 starts on the word after string i, the first at
+// word 0 -- whichever of the Push forms appended them.  Their sizes are kept a second time as 16-bit numbers (saturated):
+// a batch in which every string is shorter than 65 536 bytes can be described to the device by those alone
+// (vkmr_hip_metadata_from_sizes_async), 2 bytes per string over PCIe instead of 8.
+//
 // A Batch is what the reference's vkmr::Batch is (src/vkmr/Batches.h:31-129): strings
 // packed back to back on 4-byte boundaries in a data buffer, plus one {start word,
 // size bytes} metadata entry per string, in memory the GPU side can consume.  On
@@ -78,6 +83,11 @@ public:
     const vkmr_metadata* HostMeta() const { return m_meta; }
     uint32_t* DeviceData() const { return m_ddata; }
     vkmr_metadata* DeviceMeta() const { return m_dmeta; }
+    // the 16-bit sizes: usable in place of the metadata when no string reaches 65 536 bytes
+    bool SizesSuffice() const { return m_sizes != nullptr && m_longest < 0xFFFFu; }
+    const uint16_t* HostSizes() const { return m_sizes; }
+    uint16_t* DeviceSizes() const { return m_dsizes; }
+    void* DeviceSizesScratch() const { return m_dscratch; }
 
 private:
     void Release();
@@ -88,6 +98,11 @@ private:
     vkmr_metadata* m_meta = nullptr;   // pinned host, meta capacity
     uint32_t* m_ddata = nullptr;       // HBM
     vkmr_metadata* m_dmeta = nullptr;  // HBM
+    uint16_t* m_sizes = nullptr;       // pinned host, meta capacity
+    uint16_t* m_dsizes = nullptr;      // HBM
+    void* m_dscratch = nullptr;        // HBM, vkmr_hip_sizes_scratch_bytes(meta capacity)
+    size_t m_longest = 0;              // longest string appended so far
+    void NoteSizes(size_t first, size_t count);   // sizes[first, first + count) <- meta, m_longest
     size_t m_cap_words = 0, m_cap_count = 0;
     size_t m_count = 0, m_words = 0, m_bytes = 0;
     number_type m_number = 0xFFFFFFFFu;
@@ -118,7 +133,7 @@ public:
     void Reshape(size_t data_bytes, size_t meta_count);
 
 private:
-    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; size_t words, count; };
+    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; size_t words, count; uint16_t* sizes; uint16_t* dsizes; void* dscratch; };
     void Free(Buffers& b);
     bool Allocate(size_t words, size_t count, Buffers* out);
     void JoinPrefetch();

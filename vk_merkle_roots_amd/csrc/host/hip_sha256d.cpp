@@ -32,6 +32,7 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_SLICE_BUDGET")) c.slice_budget = (size_t)atol(e);
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
     if (const char* e = getenv("VKMR_PROOF_INDEX")) c.proof_index = atoll(e);
+    if (const char* e = getenv("VKMR_SEND_METADATA")) c.send_sizes = atoi(e) == 0;
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -149,7 +150,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
     auto set_up = [failed, warm_bytes](PerDevice* p) {
         if (vkmr_hip_stream_create(p->dev, &p->map_stream) != VKMR_OK || vkmr_hip_warm_up(p->dev, p->map_stream, VKMR_WARM_KERNELS, 0) != VKMR_OK)
             return failed("map stream");
-        if (vkmr_hip_stream_create(p->dev, &p->copy_stream) != VKMR_OK || vkmr_hip_warm_up(p->dev, p->copy_stream, VKMR_WARM_COPY, warm_bytes) != VKMR_OK)
+        if (vkmr_hip_stream_create(p->dev, &p->copy_stream) != VKMR_OK || vkmr_hip_warm_up(p->dev, p->copy_stream, VKMR_WARM_COPY | VKMR_WARM_KERNELS, warm_bytes) != VKMR_OK)
             return failed("copy stream");
         p->reduce_stream = p->map_stream;
     };
@@ -170,7 +171,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
         m_ok = false;
     }
     m_pool.reset(new ForkJoin(cfg.pack_threads > 1 ? cfg.pack_threads - 1 : 0));
-    m_mappings = Mappings::New(cfg.verbose);
+    m_mappings = Mappings::New(cfg.verbose, cfg.send_sizes);
     // slices and reductions are made when the first strings arrive: their size is chosen then (EnsureGeometry)
 }
 

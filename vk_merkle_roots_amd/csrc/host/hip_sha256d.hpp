@@ -41,10 +41,12 @@ struct HipConfig {
                                      // reduction and re-uses its slice instead of allocating another
     unsigned pack_threads = 0;       // threads packing large input spans (0 = min(16, hardware threads): 0.23 s with 8,
                                      // 0.20 s with 16 on 2^25 strings, profiles/r02_end_to_end_stdin.txt)
+    bool send_sizes = true;          // batches of strings shorter than 65 536 bytes cross PCIe as data + 2 bytes per string; the {start, size}
+                                     // entries are written on the device (VKMR_SEND_METADATA=1 sends the 8-byte entries instead, as the reference does)
     long long proof_index = -1;      // >= 0: also produce the Merkle proof of that leaf (0-based, stream order; README.md:118-120)
     bool verbose = false;            // per-op log lines like the reference prints
     static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_BATCH_MAX_MB, VKMR_MAX_INFLIGHT,
-                                     // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_PROOF_INDEX, VKMR_VERBOSE
+                                     // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_SEND_METADATA, VKMR_PROOF_INDEX, VKMR_VERBOSE
 };
 
 class HipSha256D {

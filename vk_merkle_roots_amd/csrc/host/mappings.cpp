@@ -18,7 +18,7 @@ struct Mapping {
 
 class MappingsImpl : public Mappings {
 public:
-    explicit MappingsImpl(bool verbose) : m_verbose(verbose) {}
+    MappingsImpl(bool verbose, bool send_sizes) : m_verbose(verbose), m_send_sizes(send_sizes) {}
     ~MappingsImpl() override
     {
         WaitFor();
@@ -46,9 +46,17 @@ public:
             timing::Scope ts(timing::MAP_COPIES);
             if (r == VKMR_OK)
                 r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
-            if (r == VKMR_OK)
+            if (r == VKMR_OK && m_send_sizes && batch.SizesSuffice()) {
+                // 2 bytes per string over the link instead of 8: the entries are written on the device from the sizes
+                // (the strings of a batch lie back to back from word 0: batches.hpp)
+                r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceSizes(), batch.HostSizes(), batch.Count() * sizeof(uint16_t));
+                if (r == VKMR_OK)
+                    r = vkmr_hip_metadata_from_sizes_async(m.dev, copy_stream, batch.DeviceSizes(), (uint32_t)batch.Count(), 0u,
+                                                           batch.DeviceSizesScratch(), batch.DeviceMeta());
+            } else if (r == VKMR_OK) {
                 r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceMeta(), batch.HostMeta(),
                                               batch.Count() * sizeof(vkmr_metadata));
+            }
         }
         if (r == VKMR_OK && copy_stream != stream) {
             r = vkmr_hip_event_record(m.dev, m.copied, copy_stream);
@@ -128,6 +136,7 @@ private:
     }
 
     bool m_verbose;
+    bool m_send_sizes;   // describe a batch to the device by its 16-bit sizes when they suffice (HipConfig::send_sizes)
     bool m_failed = false;
     std::vector<Mapping> m_inflight;
     std::vector<std::pair<int, vkmr_event>> m_spare;
@@ -135,6 +144,6 @@ private:
 
 }  // namespace
 
-std::unique_ptr<Mappings> Mappings::New(bool verbose) { return std::unique_ptr<Mappings>(new MappingsImpl(verbose)); }
+std::unique_ptr<Mappings> Mappings::New(bool verbose, bool send_sizes) { return std::unique_ptr<Mappings>(new MappingsImpl(verbose, send_sizes)); }
 
 }  // namespace vkmr

@@ -41,7 +41,9 @@ public:
     // run cannot produce a root)
     virtual bool Failed() const = 0;
 
-    static std::unique_ptr<Mappings> New(bool verbose);
+    // send_sizes: a batch whose strings are all shorter than 65 536 bytes goes to the device as data + 16-bit sizes, the
+    // metadata entries are written there (vkmr_hip_metadata_from_sizes_async); otherwise data + entries, as the reference sends them
+    static std::unique_ptr<Mappings> New(bool verbose, bool send_sizes = true);
 };
 
 // Reduces slices of device memory to their sub-tree roots and combines the roots.

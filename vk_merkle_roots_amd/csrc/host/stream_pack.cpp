@@ -45,7 +45,7 @@ PackResult PackLinesPortable(const uint8_t* buf, size_t len, bool final, uint32_
 
 LineCount CountLinesPortable(const uint8_t* buf, size_t len)
 {
-    LineCount c = {0, 0, 0, 0, false};
+    LineCount c = {0, 0, 0, 0, false, 0};
     size_t pos = 0;
     while (pos < len) {
         const uint8_t* nl = static_cast<const uint8_t*>(memchr(buf + pos, '\n', len - pos));
@@ -83,16 +83,19 @@ namespace {
 // What the lines of an index add up to.  Line i spans (ends[i-1], ends[i]); the first starts at 0.
 LineCount totals_of(const LineIndex& ix)
 {
-    LineCount c = {0, 0, 0, 0, false};
+    LineCount c = {0, 0, 0, 0, false, 0};
     const uint32_t* e = ix.ends;
     const size_t k = ix.count;
     if (k == 0) return c;
     uint64_t strings = e[0] != 0, words = ((uint64_t)e[0] + 3u) >> 2;
+    uint32_t longest = e[0];
     for (size_t i = 1; i < k; ++i) {
         const uint32_t n = e[i] - e[i - 1] - 1u;
         strings += n != 0;
         words += (n + 3u) >> 2;
+        longest = n > longest ? n : longest;
     }
+    c.longest = longest;
     c.strings = strings;
     c.words = words;
     c.bytes = (uint64_t)e[k - 1] + 1u - k;   // every line but its newline
@@ -118,7 +121,7 @@ LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix)
 }
 
 void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
-                         vkmr_metadata* meta)
+                         vkmr_metadata* meta, uint16_t* sizes)
 {
     (void)len; (void)end_word;
     uint64_t w = first_word;
@@ -130,6 +133,7 @@ void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, ui
             const uint32_t nw = (n + 3u) >> 2;
             meta[s].start = (uint32_t)w;
             meta[s].size = n;
+            if (sizes) sizes[s] = (uint16_t)(n < 0xFFFFu ? n : 0xFFFFu);
             ++s;
             data[w + nw - 1] = 0u;
             memcpy(data + w, buf + start, n);
@@ -159,7 +163,7 @@ __attribute__((target("avx2"))) inline uint64_t newline_mask64(const uint8_t* p)
 
 __attribute__((target("avx2"))) LineCount CountLinesAvx2(const uint8_t* buf, size_t len)
 {
-    LineCount c = {0, 0, 0, 0, false};
+    LineCount c = {0, 0, 0, 0, false, 0};
     size_t line = 0;   // start of the current line
     size_t blk = 0;
     for (; blk + 64 <= len; blk += 64) {
@@ -265,10 +269,13 @@ __attribute__((target("avx2,bmi,popcnt"))) LineCount IndexLinesAvx2(const uint8_
 // is overwritten by the next line, and the bytes of its last word beyond its end are cleared afterwards -- as long as
 // that stays inside this part's input and this part's words; longer lines, and the last few of a part, go through memcpy.
 __attribute__((target("avx2"))) void PackIndexedAvx2(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word,
-                                                     uint64_t end_word, vkmr_metadata* meta)
+                                                     uint64_t end_word, vkmr_metadata* meta, uint16_t* sizes)
 {
     uint64_t w = first_word;
     vkmr_metadata* mo = meta;
+    uint16_t scrap;
+    uint16_t* so = sizes ? sizes : &scrap;
+    const size_t so_step = sizes ? 1 : 0;
     uint32_t start = 0;
     const uint32_t* ends = ix.ends;
     for (size_t i = 0; i < ix.count; ++i) {
@@ -279,6 +286,8 @@ __attribute__((target("avx2"))) void PackIndexedAvx2(const uint8_t* buf, size_t 
             mo->start = (uint32_t)w;
             mo->size = n;
             ++mo;
+            *so = (uint16_t)(n < 0xFFFFu ? n : 0xFFFFu);
+            so += so_step;
             const uint8_t* src = buf + start;
             uint8_t* dst = reinterpret_cast<uint8_t*>(data + w);
             if (n <= 128u && (size_t)start + 128u <= len && w + 32u <= end_word) {
@@ -335,12 +344,13 @@ LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix)
     return IndexLinesPortable(buf, len, ix);
 }
 
-void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word, vkmr_metadata* meta)
+void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word, vkmr_metadata* meta,
+                 uint16_t* sizes)
 {
 #ifdef VKMR_HAVE_AVX2_PATH
-    if (have_avx2()) return PackIndexedAvx2(buf, len, ix, data, first_word, end_word, meta);
+    if (have_avx2()) return PackIndexedAvx2(buf, len, ix, data, first_word, end_word, meta, sizes);
 #endif
-    PackIndexedPortable(buf, len, ix, data, first_word, end_word, meta);
+    PackIndexedPortable(buf, len, ix, data, first_word, end_word, meta, sizes);
 }
 
 }  // namespace vkmr

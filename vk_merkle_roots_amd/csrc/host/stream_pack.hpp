@@ -31,14 +31,15 @@ PackResult PackLines(const uint8_t* buf, size_t len, bool final, uint32_t* data,
 
 // What PackLines would append for buf[0,len) with final = true, without writing anything
 // (first pass of the parallel packer).
-struct LineCount { uint64_t strings, words, bytes, empties; bool too_long; };
+struct LineCount { uint64_t strings, words, bytes, empties; bool too_long; uint32_t longest = 0; };   // longest: IndexLines only
 LineCount CountLines(const uint8_t* buf, size_t len);
 
 // Indexed two-pass form, what the parallel packer runs on each part of a span (Batch::PushLinesParallel): pass 1 records
 // where every line of the part ends and returns what the part will append -- the prefix sums over the parts give every
 // part its place in the batch -- and pass 2 packs from that record without looking for newlines again.
 //   IndexLines   ends[i] = offset of the i-th '\n' of buf[0,len); an unterminated last line ends at len.  len < 2^32 - 64.
-//   PackIndexed  appends the non-empty lines at data[first_word ...) / meta[0 ...); writes nothing at or beyond
+//   PackIndexed  appends the non-empty lines at data[first_word ...) / meta[0 ...), and their sizes as 16-bit numbers
+//                (saturated at 65 535) at sizes[0 ...) when that is not null; writes nothing at or beyond
 //                data[end_word] (the next part's words are another thread's) and reads nothing beyond buf[len).
 // Same words and metadata as PackLines(final = true) on the same bytes (tests/test_host_tools.py, test_host_fuzz.py).
 struct LineIndex {
@@ -53,10 +54,10 @@ struct LineIndex {
 };
 LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix);
 void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
-                 vkmr_metadata* meta);
+                 vkmr_metadata* meta, uint16_t* sizes = nullptr);
 LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix);
 void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
-                         vkmr_metadata* meta);
+                         vkmr_metadata* meta, uint16_t* sizes = nullptr);
 
 // The portable forms (one memchr per line).  PackLines / CountLines use AVX2 forms where the CPU has them (the newline
 // positions of 64 input bytes at a time); these stay as the reference the tests compare them with.

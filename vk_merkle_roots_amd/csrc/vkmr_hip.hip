@@ -23,6 +23,7 @@
 using vkmr_dev::Node;
 
 #include "map_kernel.hpp"
+#include "meta_kernels.hpp"
 #include "reduce_kernels.hpp"
 #include "reduce_plan.hpp"
 
@@ -353,6 +354,29 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
         hipLaunchKernelGGL((VKMR_MAP_STAGED_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
     }
     g_last_map_tile = tile;
+    VKMR_TRY(hipGetLastError());
+    return VKMR_OK;
+}
+
+// ---- metadata from sizes (meta_kernels.hpp) ---------------------------------------------------------------------------
+size_t vkmr_hip_sizes_scratch_bytes(uint32_t count)
+{
+    return ((size_t)(((uint64_t)count + VKMR_SIZES_BLOCK - 1) / VKMR_SIZES_BLOCK) + 1u) * sizeof(uint32_t);
+}
+
+vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream s, const uint16_t* sizes_dev, uint32_t count, uint32_t first_word,
+                                               void* scratch_dev, vkmr_metadata* meta_dev)
+{
+    if (count == 0) return VKMR_OK;
+    if (!sizes_dev || !scratch_dev || !meta_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_metadata_from_sizes_async: null pointer");
+    if ((reinterpret_cast<uintptr_t>(sizes_dev) & 15u) || (reinterpret_cast<uintptr_t>(meta_dev) & 15u))
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_metadata_from_sizes_async: sizes and metadata must be 16-byte aligned");
+    VKMR_TRY(hipSetDevice(dev));
+    const uint32_t nblocks = (uint32_t)(((uint64_t)count + VKMR_SIZES_BLOCK - 1) / VKMR_SIZES_BLOCK);
+    uint32_t* blocks = static_cast<uint32_t*>(scratch_dev);
+    hipLaunchKernelGGL(sizes_block_words_kernel, dim3(nblocks), dim3(VKMR_SIZES_THREADS), 0, S(s), sizes_dev, count, blocks);
+    hipLaunchKernelGGL(sizes_block_starts_kernel, dim3(1), dim3(VKMR_SIZES_THREADS), 0, S(s), blocks, nblocks, first_word);
+    hipLaunchKernelGGL(sizes_expand_kernel, dim3(nblocks), dim3(VKMR_SIZES_THREADS), 0, S(s), sizes_dev, count, (const uint32_t*)blocks, meta_dev);
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
 }
