@@ -187,8 +187,11 @@ def pipeline_rate(vk, batch, bstr, slice_log2, device=0, runs=3):
         times.append(secs.value)
         root = hexbuf.value.decode()
     dt = float(np.median(times[1:]))
-    return {"leaf_hashes_per_s": batch.count / dt, "ms": dt * 1e3, "h2d_GBps": (batch.words * 4 + batch.count * 8) / dt / 1e9, "root_hex": root,
-            "runs_ms": [t * 1e3 for t in times]}
+    # what crosses the link: the packed words and, per string, its 16-bit size (the entries are written on the device:
+    # vkmr_hip_metadata_from_sizes_async) -- or the 8-byte entry when a string reaches 65 535 bytes or VKMR_SEND_METADATA=1
+    per_string = 8 if (os.environ.get("VKMR_SEND_METADATA", "0") not in ("", "0") or int(batch.meta[:, 1].max()) >= 65535) else 2
+    return {"leaf_hashes_per_s": batch.count / dt, "ms": dt * 1e3, "h2d_GBps": (batch.words * 4 + batch.count * per_string) / dt / 1e9,
+            "h2d_bytes_per_string_of_metadata": per_string, "root_hex": root, "runs_ms": [t * 1e3 for t in times]}
 
 
 def from_file_rate(seed, count, maxlen, device, runs=3, timeout_s=300):
@@ -727,6 +730,7 @@ def main():
             pl_bstr = min(n, 1 << 23)   # the stream processor's shape: batches small enough for copies to hide behind kernels
             pl = pipeline_rate(vk, batch, pl_bstr, slice_log2 if nslices > 1 else min(slice_log2, 23), device=local_rank)
             out["pipeline_pcie_inclusive"] = {"leaf_hashes_per_s": pl["leaf_hashes_per_s"], "ms": pl["ms"], "h2d_GBps": pl["h2d_GBps"],
+                                              "h2d_bytes_per_string_of_metadata": pl["h2d_bytes_per_string_of_metadata"],
                                               "root_matches": pl["root_hex"] == root_hex, "runs_ms": pl["runs_ms"],
                                               "what": "libvkmr_pipeline.so: strings staged in the C++ stream processor's pinned batches, then its own "
                                                       "schedule -- per batch H2D on the copy stream and the map kernel behind it, slices of 2^23 to "
