@@ -736,7 +736,10 @@ def main():
                                                       "schedule -- per batch H2D on the copy stream and the map kernel behind it, slices of 2^23 to "
                                                       "Reductions as they fill, combine on the device (Mappings::Map / Reductions of `vkmr hip:0`)"}
         if world == 1 and not a.no_pipeline and not a.levels_variant:
-            ff = from_file_rate(a.seed, n, a.maxlen, local_rank)
+            try:
+                ff = from_file_rate(a.seed, n, a.maxlen, local_rank)
+            except Exception as e:   # no room for the stream in the temporary directory, a time-out ...: the leg is reported as failed, the line is still printed
+                ff = {"error": f"{type(e).__name__}: {e}"[:300]}
             if "root_hex" in ff:
                 ff["root_matches"] = ff.pop("root_hex") == root_hex and ff["items"] == n
             out["from_file_on_stdin"] = ff
