@@ -106,6 +106,8 @@ def test_hip_backend_golden_streams(native, golden):
     {"VKMR_SLICE_LOG2": "12", "VKMR_BATCH_BYTES": "20000", "VKMR_MAX_INFLIGHT": "1"},
     {"VKMR_SLICE_LOG2": "16", "VKMR_BATCH_MB": "1", "VKMR_VERBOSE": "1"},
     {"VKMR_SLICE_LOG2": "20", "VKMR_BATCH_MB": "4"},
+    {"VKMR_SEND_METADATA": "1"},                                   # batches cross as data + 8-byte entries, as the reference sends them
+    {"VKMR_SEND_METADATA": "1", "VKMR_SLICE_LOG2": "11", "VKMR_BATCH_BYTES": "50000"},
 ])
 def test_hip_backend_small_slices_and_batches(native, golden, env):
     """Many batches per slice, many slices, back-pressure: always the golden root."""
