@@ -209,6 +209,37 @@ vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream, const uint1
     return VKMR_OK;
 }
 
+size_t vkmr_hip_split_scratch_bytes(uint32_t text_bytes, uint32_t meta_capacity) { return (size_t)text_bytes / 512u + (size_t)meta_capacity * 8u + 4096u; }
+vkmr_status vkmr_hip_split_text_async(int dev, vkmr_stream, const uint8_t* text, uint32_t text_bytes, void* scratch, uint32_t* data, uint64_t data_capacity_words,
+                                      vkmr_metadata* meta, uint32_t meta_capacity, uint32_t* result)
+{
+    if (!dev_ok(dev) || !result || room_at(result) < 12) return fail(VKMR_ERR_INVALID, "split_text");
+    result[0] = result[1] = result[2] = 0;
+    if (text_bytes == 0) return VKMR_OK;
+    if (!text || !scratch || !data || !meta || room_at(text) < text_bytes || room_at(meta) < (size_t)meta_capacity * 8 || room_at(data) < data_capacity_words * 4)
+        return fail(VKMR_ERR_INVALID, "split_text: a buffer is not (large enough) device memory");
+    uint64_t w = 0;
+    uint32_t k = 0, open_at = 0;
+    for (uint32_t i = 0; i < text_bytes; ++i) {
+        if (text[i] != '\n') continue;
+        const uint32_t n = i - open_at;
+        if (n) {
+            const uint64_t nw = (n + 3u) / 4u;
+            if (k >= meta_capacity || w + nw > data_capacity_words) { result[2] = 1; return VKMR_OK; }
+            meta[k].start = (uint32_t)w;
+            meta[k].size = n;
+            data[w + nw - 1] = 0;
+            memcpy(data + w, text + open_at, n);
+            w += nw;
+            ++k;
+        }
+        open_at = i + 1;
+    }
+    result[0] = k;
+    result[1] = (uint32_t)w;
+    return VKMR_OK;
+}
+
 vkmr_status vkmr_hip_warm_up(int dev, vkmr_stream, unsigned, size_t) { return dev_ok(dev) ? VKMR_OK : fail(VKMR_ERR_INVALID, "warm_up"); }
 
 vkmr_status vkmr_hip_stream_create(int dev, vkmr_stream* out)

@@ -50,6 +50,74 @@ def test_metadata_from_sizes(gpu):
     assert gpu.lib.vkmr_hip_metadata_from_sizes_async(gpu.index, gpu.stream, None, 5, 0, None, None) < 0       # null pointers are refused
 
 
+def _split_on_gpu(gpu, text, meta_capacity=None, data_capacity_words=None):
+    import vk_merkle_roots_amd as vk
+    n = len(text)
+    lines = text.count(b"\n")
+    meta_capacity = meta_capacity if meta_capacity is not None else max(1, lines)
+    data_capacity_words = data_capacity_words if data_capacity_words is not None else n // 4 + lines + 4
+    padded = np.frombuffer(text + b"\xAA" * (48 - n % 16), dtype=np.uint8)      # readable (and not zero) behind the text
+    d_text = gpu.upload(padded)
+    d_data = gpu.alloc(4 * data_capacity_words + 64)
+    d_meta = gpu.alloc(8 * meta_capacity + 16)
+    d_scratch = gpu.alloc(gpu.lib.vkmr_hip_split_scratch_bytes(n, meta_capacity))
+    d_result = gpu.alloc(16)
+    vk.check(gpu.lib.vkmr_hip_memset_async(gpu.index, gpu.stream, d_data.ptr, 0xCD, 4 * data_capacity_words + 64), "memset")
+    vk.check(gpu.lib.vkmr_hip_split_text_async(gpu.index, gpu.stream, d_text.ptr, n, d_scratch.ptr, d_data.ptr, data_capacity_words, d_meta.ptr, meta_capacity,
+                                               d_result.ptr), "split")
+    strings, words, status = (int(x) for x in gpu.download(d_result, 12))
+    meta = gpu.download(d_meta, 8 * min(strings, meta_capacity)).reshape(-1, 2) if strings else np.zeros((0, 2), np.uint32)
+    data = gpu.download(d_data, 4 * data_capacity_words + 64)
+    for b in (d_text, d_data, d_meta, d_scratch, d_result):
+        b.free()
+    return strings, words, status, meta, data
+
+
+def test_split_text_on_the_device(gpu):
+    """vkmr_hip_split_text_async against the host packer (the memchr-and-memcpy form, which the oracle's line rules pin):
+    same strings, same entries, same packed words with zero padding, nothing written behind them -- for rndm-like text,
+    one- and two-byte lines, empty lines in runs and at both ends, CRs, lines that straddle the kernels' 16-byte pieces and
+    4 KiB blocks, lines of 5 000 and 70 000 bytes, a text of one newline, and 40 MB of text."""
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    rng = np.random.default_rng(123)
+
+    def rand_lines(count, lo, hi, alphabet=(33, 126)):
+        return b"".join(rng.integers(alphabet[0], alphabet[1] + 1, size=int(k), dtype=np.uint8).tobytes() + b"\n" for k in rng.integers(lo, hi + 1, size=count))
+
+    texts = [b"\n", b"a\n", b"\n\n\nab\n\n", b"x" * 15 + b"\n" + b"y" * 16 + b"\n" + b"z" * 17 + b"\n", b"q\r\n\r\n",
+             rand_lines(5000, 0, 127), rand_lines(20000, 0, 3), rand_lines(3000, 1, 1), rand_lines(300, 4000, 5000),
+             b"head\n" + b"L" * 70000 + b"\n" + rand_lines(100, 0, 40) + b"M" * 4095 + b"\n" + b"N" * 4096 + b"\n" + b"O" * 4097 + b"\n",
+             rand_lines(50, 0, 20, alphabet=(9, 13)),                          # tabs, newlines and CRs only: runs of empty lines
+             rand_lines(600000, 0, 127)]
+    for text in texts:
+        buf = np.frombuffer(text, dtype=np.uint8)
+        lines = text.count(b"\n")
+        ref_data = np.zeros(len(text) // 4 + lines + 4, dtype=np.uint32)
+        ref_meta = np.zeros((lines + 1, 2), dtype=np.uint32)
+        wu, bt = C_u64(), C_u64()
+        want = h.vkmr_host_pack_lines_portable(buf.ctypes.data, len(text), ref_data.ctypes.data, len(ref_data), ref_meta.ctypes.data, len(ref_meta), wu, bt)
+        strings, words, status, meta, data = _split_on_gpu(gpu, text)
+        assert (strings, words, status) == (want, wu.value, 0), (len(text), strings, want)
+        assert np.array_equal(meta, ref_meta[:want])
+        assert np.array_equal(data[:words], ref_data[:words])
+        assert (data[words:] == 0xCDCDCDCD).all()                              # nothing written behind the strings' words
+    # what does not fit is reported, not written past the capacities
+    text = rand_lines(1000, 10, 50)
+    strings, words, status, meta, data = _split_on_gpu(gpu, text, meta_capacity=999)
+    assert status == 1
+    strings, words, status, meta, data = _split_on_gpu(gpu, text, data_capacity_words=100)
+    assert status == 1 and strings == 1000 and (data == 0xCDCDCDCD).all()
+    # an unterminated tail is not a string (the caller appends the newline): "ab\ncd" holds one
+    strings, words, status, meta, data = _split_on_gpu(gpu, b"ab\ncd")
+    assert (strings, words, status) == (1, 1, 0)
+
+
+def C_u64():
+    import ctypes
+    return ctypes.c_uint64()
+
+
 def test_warm_up_leaves_no_trace(gpu, oracle):
     """vkmr_hip_warm_up (kernels, copy engine, both, neither; small and large copies; the device's stream and a new one)
     returns VKMR_OK, and launches after it give what they give without it."""

@@ -37,6 +37,9 @@ SIGNATURES = {
     "vkmr_hip_stream_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vkmr_hip_metadata_from_sizes_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_sizes_scratch_bytes": (C.c_size_t, [C.c_uint32]),
+    "vkmr_hip_split_text_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                            C.c_void_p]),
+    "vkmr_hip_split_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "vkmr_hip_warm_up": (C.c_int, [C.c_int, C.c_void_p, C.c_uint, C.c_size_t]),
     "vkmr_hip_stream_destroy": (C.c_int, [C.c_int, C.c_void_p]),
     "vkmr_hip_stream_sync": (C.c_int, [C.c_int, C.c_void_p]),

@@ -6,6 +6,8 @@
 //                       reduce_collapse_kernel / reduce_tail_kernel   the latency-bound top, __shfl_down
 //                       reduce_level_kernel    one level per launch, cross-check    (SHA-256.comp:393-434)
 //   sha256d_device.hpp  the SHA-256 round / compression building blocks
+//   meta_kernels.hpp    sizes_*_kernel         metadata entries from 16-bit sizes   (Batches.cpp:64-121)
+//   split_kernels.hpp   split_*_kernel         text -> packed batch on the device   (Inputs.cpp:75-101, Batches.cpp:64-121)
 //
 // Host side: plain launches on the caller's stream; no allocation, no sync inside
 // the *_async entry points.
@@ -24,6 +26,7 @@ using vkmr_dev::Node;
 
 #include "map_kernel.hpp"
 #include "meta_kernels.hpp"
+#include "split_kernels.hpp"
 #include "reduce_kernels.hpp"
 #include "reduce_plan.hpp"
 
@@ -377,6 +380,55 @@ vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream s, const uin
     hipLaunchKernelGGL(sizes_block_words_kernel, dim3(nblocks), dim3(VKMR_SIZES_THREADS), 0, S(s), sizes_dev, count, blocks);
     hipLaunchKernelGGL(sizes_block_starts_kernel, dim3(1), dim3(VKMR_SIZES_THREADS), 0, S(s), blocks, nblocks, first_word);
     hipLaunchKernelGGL(sizes_expand_kernel, dim3(nblocks), dim3(VKMR_SIZES_THREADS), 0, S(s), sizes_dev, count, (const uint32_t*)blocks, meta_dev);
+    VKMR_TRY(hipGetLastError());
+    return VKMR_OK;
+}
+
+// ---- text -> packed batch (split_kernels.hpp) ---------------------------------------------------------------------------
+namespace {
+struct SplitScratch { uint32_t *blk_count, *blk_after, *wblocks; vkmr_split::Line* lines; size_t bytes; };
+SplitScratch split_scratch(void* base, uint32_t text_bytes, uint32_t meta_capacity)
+{
+    auto up = [](size_t n) { return (n + 255u) & ~(size_t)255u; };
+    const size_t nb = ((size_t)text_bytes + VKMR_SPLIT_BLOCK - 1) / VKMR_SPLIT_BLOCK + 1, nwb = ((size_t)meta_capacity + VKMR_SIZES_BLOCK - 1) / VKMR_SIZES_BLOCK + 1;
+    char* p = static_cast<char*>(base);
+    SplitScratch sc;
+    sc.blk_count = reinterpret_cast<uint32_t*>(p); p += up(nb * 4);
+    sc.blk_after = reinterpret_cast<uint32_t*>(p); p += up(nb * 4);
+    sc.wblocks = reinterpret_cast<uint32_t*>(p); p += up(nwb * 4);
+    sc.lines = reinterpret_cast<vkmr_split::Line*>(p); p += up((size_t)meta_capacity * sizeof(vkmr_split::Line));
+    sc.bytes = (size_t)(p - static_cast<char*>(base));
+    return sc;
+}
+}  // namespace
+
+size_t vkmr_hip_split_scratch_bytes(uint32_t text_bytes, uint32_t meta_capacity) { return split_scratch(nullptr, text_bytes, meta_capacity).bytes; }
+
+vkmr_status vkmr_hip_split_text_async(int dev, vkmr_stream s, const uint8_t* text_dev, uint32_t text_bytes, void* scratch_dev, uint32_t* data_dev,
+                                      uint64_t data_capacity_words, vkmr_metadata* meta_dev, uint32_t meta_capacity, uint32_t* result_dev)
+{
+    if (!result_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_split_text_async: null result pointer");
+    VKMR_TRY(hipSetDevice(dev));
+    VKMR_TRY(hipMemsetAsync(result_dev, 0, 3 * sizeof(uint32_t), S(s)));
+    if (text_bytes == 0) return VKMR_OK;
+    if (!text_dev || !scratch_dev || !data_dev || !meta_dev || meta_capacity == 0)
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_split_text_async: null pointer");
+    if ((reinterpret_cast<uintptr_t>(text_dev) & 15u) || text_bytes > 0xFFFFFFE0u)
+        return fail(VKMR_ERR_INVALID, "vkmr_hip_split_text_async: the text must be 16-byte aligned and shorter than 4 GiB");
+    const SplitScratch sc = split_scratch(scratch_dev, text_bytes, meta_capacity);
+    const uint32_t nb = (uint32_t)(((uint64_t)text_bytes + VKMR_SPLIT_BLOCK - 1) / VKMR_SPLIT_BLOCK);
+    const uint32_t nwb = (uint32_t)(((uint64_t)meta_capacity + VKMR_SIZES_BLOCK - 1) / VKMR_SIZES_BLOCK);
+    hipLaunchKernelGGL(split_count_kernel, dim3(nb), dim3(VKMR_SPLIT_THREADS), 0, S(s), text_dev, text_bytes, sc.blk_count, sc.blk_after);
+    hipLaunchKernelGGL(split_scan_kernel, dim3(1), dim3(VKMR_SPLIT_THREADS), 0, S(s), sc.blk_count, sc.blk_after, nb, result_dev);
+    hipLaunchKernelGGL(split_lines_kernel, dim3(nb), dim3(VKMR_SPLIT_THREADS), 0, S(s), text_dev, text_bytes, (const uint32_t*)sc.blk_count,
+                       (const uint32_t*)sc.blk_after, sc.lines, meta_capacity, result_dev);
+    hipLaunchKernelGGL(split_block_words_kernel, dim3(nwb), dim3(VKMR_SIZES_THREADS), 0, S(s), (const vkmr_split::Line*)sc.lines, (const uint32_t*)result_dev,
+                       meta_capacity, sc.wblocks);
+    hipLaunchKernelGGL(sizes_block_starts_kernel, dim3(1), dim3(VKMR_SIZES_THREADS), 0, S(s), sc.wblocks, nwb, 0u);
+    hipLaunchKernelGGL(split_expand_kernel, dim3(nwb), dim3(VKMR_SIZES_THREADS), 0, S(s), (const vkmr_split::Line*)sc.lines, result_dev, meta_capacity,
+                       (const uint32_t*)sc.wblocks, meta_dev);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((meta_capacity + 255u) / 256u), dim3(256), 0, S(s), text_dev, (const vkmr_split::Line*)sc.lines,
+                       (const vkmr_metadata*)meta_dev, result_dev, meta_capacity, data_dev, data_capacity_words);
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
 }
