@@ -188,9 +188,11 @@ vkmr_status vkmr_hip_memcpy_d2h_async(int, vkmr_stream, void* dst, const void* s
 // (the batch crossed as 16-bit sizes) and how many did not (it crossed as entries)
 static std::atomic<unsigned long> g_from_sizes{0}, g_maps{0};
 static const vkmr_metadata* g_last_expanded = nullptr;
+static std::atomic<unsigned long> g_splits{0};
 static void report_forms()
 {
     fprintf(stderr, "fake: batches described by sizes %lu, by entries %lu\n", g_from_sizes.load(), g_maps.load() - g_from_sizes.load());
+    fprintf(stderr, "fake: texts split on the device %lu\n", g_splits.load());
 }
 size_t vkmr_hip_sizes_scratch_bytes(uint32_t count) { return ((size_t)count / 4096u + 2u) * 4u; }
 vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream, const uint16_t* sizes, uint32_t count, uint32_t first_word, void* scratch,
@@ -215,6 +217,7 @@ vkmr_status vkmr_hip_split_text_async(int dev, vkmr_stream, const uint8_t* text,
 {
     if (!dev_ok(dev) || !result || room_at(result) < 12) return fail(VKMR_ERR_INVALID, "split_text");
     result[0] = result[1] = result[2] = 0;
+    ++g_splits;
     if (text_bytes == 0) return VKMR_OK;
     if (!text || !scratch || !data || !meta || room_at(text) < text_bytes || room_at(meta) < (size_t)meta_capacity * 8 || room_at(data) < data_capacity_words * 4)
         return fail(VKMR_ERR_INVALID, "split_text: a buffer is not (large enough) device memory");

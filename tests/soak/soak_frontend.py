@@ -34,6 +34,8 @@ while time.time() - t0 < budget:
         del env["VKMR_BATCH_BYTES"]      # the default batches (one span of stdin each)
     if rng.integers(0, 2):
         env["VKMR_INPUT_SPAN_MB"] = str(int(rng.choice([1, 2, 5, 32])))
+    if rng.integers(0, 3) == 0:
+        env["VKMR_DEVICE_SPLIT"] = "1"     # large spans are split into strings on the device
     if rng.integers(0, 2):
         env["VKMR_SLICE_BUDGET"] = str(int(rng.integers(1, 4)))
     backend = "hip:0"

@@ -235,6 +235,9 @@ def test_device_listing_with_several_devices(native):
     {"VKMR_PACK_THREADS": "3", "VKMR_BATCH_MB": "64"},
     {"VKMR_PACK_THREADS": "16", "VKMR_INPUT_SPAN_MB": "4", "VKMR_BATCH_MB": "8", "VKMR_SLICE_LOG2": "19"},
     {"VKMR_PACK_THREADS": "1"},
+    {"VKMR_DEVICE_SPLIT": "1"},                                                                   # the text split into strings on the device
+    {"VKMR_DEVICE_SPLIT": "1", "VKMR_PACK_THREADS": "5", "VKMR_INPUT_SPAN_MB": "2", "VKMR_BATCH_MB": "3", "VKMR_SLICE_LOG2": "15"},
+    {"VKMR_DEVICE_SPLIT": "1", "VKMR_PACK_THREADS": "7", "VKMR_INPUT_SPAN_MB": "8", "VKMR_BATCH_MB": "16", "VKMR_SLICE_LOG2": "19", "VKMR_MAX_INFLIGHT": "1"},
 ])
 def test_hip_backend_mapped_file_and_parallel_packer(native, golden, tmp_path, env):
     """stdin redirected from a regular file (mapped) with the fork-join packer: spans cut at line ends,

@@ -138,3 +138,26 @@ def test_indexed_two_pass_packer_equals_the_portable_one(native, parts, first_wo
         assert got == strings and [int(v) for v in out[:3]] == [words, nbytes, empties]
         assert data.tolist() == ref_data.tolist()          # incl. the untouched words before first_word and from first_word + words on
         assert meta.tolist() == ref_meta.tolist()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.one_of(st.sampled_from([b"\n", b"\n\n\n", b"x" * 63 + b"\n", b"y" * 64, b"\n" * 70, b"z" * 130 + b"\n\n"]), st.binary(min_size=0, max_size=100)), max_size=40),
+       st.booleans())
+def test_copy_and_count_lines(native, parts, after_newline):
+    """The device-side splitter's host pass: the bytes copied as they are, newlines counted, and those that end an empty
+    line (the byte before is a newline, or the stream's start) -- both forms against a plain Python count."""
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    stream = b"".join(parts)
+    buf = np.frombuffer(stream, dtype=np.uint8) if stream else np.zeros(0, np.uint8)
+    want_nl = stream.count(b"\n")
+    prev, want_empty = after_newline, 0
+    for ch in stream:
+        want_empty += ch == 10 and prev
+        prev = ch == 10
+    for which in (0, 1):
+        dst = np.full(len(stream) + 8, 0xEE, dtype=np.uint8)
+        out = np.zeros(2, np.uint64)
+        h.vkmr_host_copy_and_count(buf.ctypes.data if len(stream) else None, len(stream), dst.ctypes.data, int(after_newline), which, out.ctypes.data)
+        assert [int(v) for v in out] == [want_nl, want_empty]
+        assert dst[:len(stream)].tobytes() == stream and (dst[len(stream):] == 0xEE).all()

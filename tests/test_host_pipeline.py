@@ -188,6 +188,39 @@ def test_hip_all_deals_one_slice_per_device_when_the_input_size_is_known(fake_vk
     assert any(l.startswith("Slices of 2^23 digests") for l in out) and [m for m in (LINE.match(l) for l in out) if m][-1].group("root") == want
 
 
+@pytest.mark.parametrize("knobs", [
+    {},
+    {"VKMR_PACK_THREADS": 5, "VKMR_INPUT_SPAN_MB": 2, "VKMR_BATCH_MB": 3, "VKMR_SLICE_LOG2": 15},     # most spans hold more strings than the slice has room for
+    {"VKMR_PACK_THREADS": 7, "VKMR_INPUT_SPAN_MB": 3, "VKMR_SLICE_LOG2": 18, "VKMR_MAX_INFLIGHT": 1},
+    {"VKMR_PACK_THREADS": 1, "VKMR_INPUT_SPAN_MB": 5, "VKMR_BATCH_MB": 4},                            # the span does not fit the batch's text area
+])
+def test_text_split_on_the_device(fake_vkmr, native, golden, oracle, knobs, tmp_path):
+    """VKMR_DEVICE_SPLIT=1: spans of 1 MiB and more are copied into pinned memory as they are (their lines counted on the
+    way), split into strings by vkmr_hip_split_text_async, and mapped; spans that do not qualify take the host packer.  The
+    golden 2^20-string stream from a file and through a pipe, and a stream with runs of empty lines, CRs and no final
+    newline, for thread counts that do not divide the spans, spans larger than the batch, and slices smaller than a span:
+    always the reference's root, items and bytes -- and the device path was taken (the fake ABI counts its calls)."""
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    stream = stream_of(native, s)
+    odd = b"\n\n" + stream[:3 << 20].replace(b"a", b"\r\n\n", 40).replace(b"b", b"\n", 5000)[:-1]
+    want_odd = oracle.root_of_stream(odd)
+    path = tmp_path / "g3.txt"
+    path.write_bytes(stream)
+    for body, want, via_file in ((stream, (s["root"], s["items"], s["bytes"]), True), (stream, (s["root"], s["items"], s["bytes"]), False), (odd, want_odd, False)):
+        exe, env = fake_vkmr
+        env = dict(env, VKMR_DEVICE_SPLIT="1", VKMR_FAKE_COUNT_FORMS="1", **{k: str(v) for k, v in knobs.items()})
+        if via_file:
+            with open(path, "rb") as f:
+                r = subprocess.run([exe, "hip:0"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        else:
+            r = subprocess.run([exe, "hip:0"], input=body, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-2000:].decode()
+        m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
+        assert (m["root"], int(m["items"]), int(m["bytes"])) == tuple(want), (knobs, via_file)
+        split = [l for l in r.stderr.decode().splitlines() if l.startswith("fake: texts split on the device")]
+        assert split and int(re.findall(r"(\d+)", split[-1])[0]) > 0, r.stderr[-300:]
+
+
 def test_batches_cross_as_sizes_or_as_entries(fake_vkmr, native, oracle):
     """A batch whose strings are all shorter than 65 536 bytes is described to the device by 16-bit sizes
     (vkmr_hip_metadata_from_sizes_async writes the entries there); one string of 65 535 bytes or more and the batch goes
@@ -275,6 +308,12 @@ def test_parallel_packer_in_the_pipeline_under_tsan(native, golden, tmp_path):
                TSAN_OPTIONS="halt_on_error=0")
     with open(path, "rb") as f:
         r = subprocess.run([exe, "hip:0"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:].decode()
+    m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
+    assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])
+    # the device-split path: the fork-join copy-and-count into the pinned text area
+    with open(path, "rb") as f:
+        r = subprocess.run([exe, "hip:0"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, VKMR_DEVICE_SPLIT="1"), timeout=900)
     assert b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:].decode()
     m = [x for x in (LINE.match(l) for l in r.stdout.decode().splitlines()) if x][-1].groupdict()
     assert (int(m["items"]), int(m["bytes"]), m["root"]) == (s["items"], s["bytes"], s["root"])

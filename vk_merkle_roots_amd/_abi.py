@@ -90,6 +90,7 @@ HOST_SIGNATURES = {
     "vkmr_host_pack_lines_portable": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vkmr_host_pack_indexed": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
+    "vkmr_host_copy_and_count": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vkmr_host_count_lines": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "vkmr_host_pack_prefix": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
 }

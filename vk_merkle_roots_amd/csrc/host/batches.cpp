@@ -21,6 +21,8 @@ Batch& Batch::operator=(Batch&& o) noexcept
         m_owner = o.m_owner; m_dev = o.m_dev;
         m_data = o.m_data; m_meta = o.m_meta; m_ddata = o.m_ddata; m_dmeta = o.m_dmeta;
         m_sizes = o.m_sizes; m_dsizes = o.m_dsizes; m_dscratch = o.m_dscratch; m_longest = o.m_longest;
+        m_dtext = o.m_dtext; m_dsplit = o.m_dsplit; m_dresult = o.m_dresult; m_hresult = o.m_hresult; m_text_bytes = o.m_text_bytes;
+        o.m_dtext = nullptr; o.m_dsplit = nullptr; o.m_dresult = nullptr; o.m_hresult = nullptr; o.m_text_bytes = 0;
         m_cap_words = o.m_cap_words; m_cap_count = o.m_cap_count;
         m_count = o.m_count; m_words = o.m_words; m_bytes = o.m_bytes; m_number = o.m_number;
         o.m_owner = nullptr; o.m_data = nullptr; o.m_meta = nullptr; o.m_ddata = nullptr; o.m_dmeta = nullptr;
@@ -36,7 +38,20 @@ void Batch::Release()
     m_owner = nullptr;
     m_data = nullptr; m_meta = nullptr; m_ddata = nullptr; m_dmeta = nullptr;
     m_sizes = nullptr; m_dsizes = nullptr; m_dscratch = nullptr;
-    m_count = m_words = m_bytes = m_longest = 0;
+    m_dtext = nullptr; m_dsplit = nullptr; m_dresult = nullptr; m_hresult = nullptr;
+    m_count = m_words = m_bytes = m_longest = m_text_bytes = 0;
+}
+
+void Batch::SetText(size_t text_bytes, size_t strings, size_t payload_bytes)
+{
+    m_text_bytes = text_bytes;
+    m_count = strings;
+    m_bytes = payload_bytes;
+    // the packed words are counted on the device; the host knows them to within 3 bytes per string: what the map launch is
+    // told (its mode goes by the average, its bounds by the total) -- never less than what the strings take
+    const size_t upper = (payload_bytes + 3 * strings) / 4;
+    m_words = upper < m_cap_words ? upper : m_cap_words;
+    m_longest = 0xFFFFu;   // the sizes are not on the host: this batch is not described by them
 }
 
 void Batch::NoteSizes(size_t first, size_t count)
@@ -232,8 +247,8 @@ void Batch::Pop(size_t count)
     }
 }
 
-Batches::Batches(int dev, size_t data_bytes)
-    : m_dev(dev), m_words(data_bytes / 4), m_count(data_bytes / sizeof(vkmr_digest)), m_live(0), m_next(0)
+Batches::Batches(int dev, size_t data_bytes, bool device_split)
+    : m_dev(dev), m_device_split(device_split), m_words(data_bytes / 4), m_count(data_bytes / sizeof(vkmr_digest)), m_live(0), m_next(0)
 {
     if (m_words > 0xFFFFFFFFull) m_words = 0xFFFFFFFFull;   // vkmr_metadata::start is a 32-bit word index
     if (m_count == 0) m_count = 1;
@@ -248,6 +263,10 @@ void Batches::Free(Buffers& b)
     vkmr_hip_device_free(m_dev, b.dmeta);
     vkmr_hip_device_free(m_dev, b.dsizes);
     vkmr_hip_device_free(m_dev, b.dscratch);
+    vkmr_hip_device_free(m_dev, b.dtext);
+    vkmr_hip_device_free(m_dev, b.dsplit);
+    vkmr_hip_device_free(m_dev, b.dresult);
+    vkmr_hip_host_free(b.hresult);
 }
 
 Batches::~Batches()
@@ -280,7 +299,18 @@ bool Batches::Allocate(size_t words, size_t count, Buffers* out)
         return false;
     }
     *out = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1), static_cast<vkmr_metadata*>(d2), words, count,
-            static_cast<uint16_t*>(h3), static_cast<uint16_t*>(d3), d4};
+            static_cast<uint16_t*>(h3), static_cast<uint16_t*>(d3), d4, nullptr, nullptr, nullptr, nullptr};
+    if (m_device_split && words * 4 < 0xFFFFFFE0ull) {   // the splitter's text area, scratch and result words; without them the batch simply cannot hold text
+        void *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr;
+        const bool ok2 = vkmr_hip_device_alloc(m_dev, words * 4 + 64, &t1) == VKMR_OK &&
+                         vkmr_hip_device_alloc(m_dev, vkmr_hip_split_scratch_bytes((uint32_t)(words * 4), (uint32_t)count32), &t2) == VKMR_OK &&
+                         vkmr_hip_device_alloc(m_dev, 16, &t3) == VKMR_OK && vkmr_hip_host_alloc(16, &t4) == VKMR_OK;
+        if (ok2) {
+            out->dtext = static_cast<uint8_t*>(t1); out->dsplit = t2; out->dresult = static_cast<uint32_t*>(t3); out->hresult = static_cast<uint32_t*>(t4);
+        } else {
+            vkmr_hip_device_free(m_dev, t1); vkmr_hip_device_free(m_dev, t2); vkmr_hip_device_free(m_dev, t3); vkmr_hip_host_free(t4);
+        }
+    }
     return true;
 }
 
@@ -326,7 +356,7 @@ void Batches::Reshape(size_t data_bytes, size_t meta_count)
 Batch Batches::New()
 {
     Batch b;
-    Buffers buf = {nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    Buffers buf = {nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool have = false;
     {
         std::unique_lock<std::mutex> lock(m_mu);
@@ -345,6 +375,7 @@ Batch Batches::New()
     b.m_owner = this; b.m_dev = m_dev;
     b.m_data = buf.data; b.m_meta = buf.meta; b.m_ddata = buf.ddata; b.m_dmeta = buf.dmeta;
     b.m_sizes = buf.sizes; b.m_dsizes = buf.dsizes; b.m_dscratch = buf.dscratch;
+    b.m_dtext = buf.dtext; b.m_dsplit = buf.dsplit; b.m_dresult = buf.dresult; b.m_hresult = buf.hresult;
     b.m_cap_words = buf.words; b.m_cap_count = buf.count;
     b.m_number = m_next++;
     ++m_live;
@@ -353,7 +384,8 @@ Batch Batches::New()
 
 void Batches::Recycle(Batch& b)
 {
-    Buffers buf = {b.m_data, b.m_meta, b.m_ddata, b.m_dmeta, b.m_cap_words, b.m_cap_count, b.m_sizes, b.m_dsizes, b.m_dscratch};
+    Buffers buf = {b.m_data, b.m_meta, b.m_ddata, b.m_dmeta, b.m_cap_words, b.m_cap_count, b.m_sizes, b.m_dsizes, b.m_dscratch,
+                   b.m_dtext, b.m_dsplit, b.m_dresult, b.m_hresult};
     if (buf.words == m_words && buf.count == m_count) {
         std::lock_guard<std::mutex> lock(m_mu);
         m_free.push_back(buf);

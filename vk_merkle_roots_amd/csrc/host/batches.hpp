@@ -52,6 +52,7 @@ public:
     bool Empty() const { return !(*this) || m_count == 0; }
     size_type RoomWords() const { return m_cap_words - m_words; }     // packed words still free
     size_type CapacityWords() const { return m_cap_words; }
+    size_type CapacityCount() const { return m_cap_count; }
     number_type Number() const { return m_number; }
     int Device() const { return m_dev; }
 
@@ -88,6 +89,19 @@ public:
     const uint16_t* HostSizes() const { return m_sizes; }
     uint16_t* DeviceSizes() const { return m_dsizes; }
     void* DeviceSizesScratch() const { return m_dscratch; }
+    // Device-side splitting (pools made with `device_split`): the batch holds raw text instead of packed strings.  The text
+    // (whole lines, ending in '\n') is written to TextArea() -- the pinned data buffer taken as bytes -- and SetText says how
+    // long it is and what it holds; the device turns it into the packed layout in its own copy of the batch
+    // (vkmr_hip_split_text_async) and reports what it found in HostSplitResult() for the owner to check.
+    bool CanHoldText() const { return m_dtext != nullptr; }
+    uint8_t* TextArea() const { return reinterpret_cast<uint8_t*>(m_data); }
+    size_t TextCapacity() const { return m_cap_words * 4; }
+    void SetText(size_t text_bytes, size_t strings, size_t payload_bytes);
+    size_t TextBytes() const { return m_text_bytes; }
+    uint8_t* DeviceText() const { return m_dtext; }
+    void* DeviceSplitScratch() const { return m_dsplit; }
+    uint32_t* DeviceSplitResult() const { return m_dresult; }
+    uint32_t* HostSplitResult() const { return m_hresult; }
 
 private:
     void Release();
@@ -101,6 +115,11 @@ private:
     uint16_t* m_sizes = nullptr;       // pinned host, meta capacity
     uint16_t* m_dsizes = nullptr;      // HBM
     void* m_dscratch = nullptr;        // HBM, vkmr_hip_sizes_scratch_bytes(meta capacity)
+    uint8_t* m_dtext = nullptr;        // HBM: the raw text of a device-split batch (pools with device_split only)
+    void* m_dsplit = nullptr;          // HBM: vkmr_hip_split_scratch_bytes
+    uint32_t* m_dresult = nullptr;     // HBM: the splitter's three result words
+    uint32_t* m_hresult = nullptr;     // pinned host: their copy
+    size_t m_text_bytes = 0;           // > 0: the batch holds that much raw text, not packed strings
     size_t m_longest = 0;              // longest string appended so far
     void NoteSizes(size_t first, size_t count);   // sizes[first, first + count) <- meta, m_longest
     size_t m_cap_words = 0, m_cap_count = 0;
@@ -113,7 +132,8 @@ class Batches {
 public:
     // data_bytes: capacity of a batch's data buffer; metadata capacity follows the
     // reference's ratio (one entry per 32 data bytes, src/vkmr/Batches.h:131-134).
-    Batches(int dev, size_t data_bytes);
+    // device_split: every batch also gets what vkmr_hip_split_text_async needs (a text area in HBM, scratch, result words)
+    Batches(int dev, size_t data_bytes, bool device_split = false);
     ~Batches();
     Batches(const Batches&) = delete;
     Batches& operator=(const Batches&) = delete;
@@ -133,11 +153,13 @@ public:
     void Reshape(size_t data_bytes, size_t meta_count);
 
 private:
-    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; size_t words, count; uint16_t* sizes; uint16_t* dsizes; void* dscratch; };
+    struct Buffers { uint32_t* data; vkmr_metadata* meta; uint32_t* ddata; vkmr_metadata* dmeta; size_t words, count; uint16_t* sizes; uint16_t* dsizes; void* dscratch;
+                     uint8_t* dtext; void* dsplit; uint32_t* dresult; uint32_t* hresult; };
     void Free(Buffers& b);
     bool Allocate(size_t words, size_t count, Buffers* out);
     void JoinPrefetch();
     int m_dev;
+    bool m_device_split = false;
     size_t m_words, m_count, m_live, m_allocations = 0;
     uint32_t m_next;
     std::vector<Buffers> m_free;

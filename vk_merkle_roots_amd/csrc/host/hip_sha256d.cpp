@@ -33,6 +33,7 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
     if (const char* e = getenv("VKMR_PROOF_INDEX")) c.proof_index = atoll(e);
     if (const char* e = getenv("VKMR_SEND_METADATA")) c.send_sizes = atoi(e) == 0;
+    if (const char* e = getenv("VKMR_DEVICE_SPLIT")) c.device_split = atoi(e) != 0;
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -119,7 +120,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
             const uint64_t need = ((cfg.expected_input_bytes + cfg.expected_input_bytes / 4 + (1u << 16)) + ((1u << 20) - 1)) & ~(uint64_t)((1u << 20) - 1);
             if (need < batch_bytes) batch_bytes = (size_t)need;
         }
-        pd.batches.reset(new Batches(d, batch_bytes));
+        pd.batches.reset(new Batches(d, batch_bytes, cfg.device_split));
         if (cfg.verbose) {
             char devname[256] = "";
             size_t free_b = 0, total_b = 0;
@@ -428,6 +429,58 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
     return m_slices.Current().Reserve(1);
 }
 
+// The device-split path (HipConfig::device_split).  The host's part is one pass: the span's bytes into the batch's pinned
+// text area (fork-join, equal byte ranges -- no line boundaries needed) with its newlines counted, so that the slice and
+// the caller's tally know how many strings there are before the device has seen a byte.
+size_t HipSha256D::Instance::PushTextForDevice(const char* text, size_t len, bool final, Tally* tally)
+{
+    Slice& slice = m_slices.Current();
+    if (!m_batch.CanHoldText() || !m_batch.Empty() || !slice || len < ((size_t)1 << 20)) return 0;
+    // the packed strings are a little larger than the text (padding to words): 7/8 of the batch's data area is taken as text,
+    // which leaves room for lines of 25 bytes on average (shorter ones: the host packer); a last line without its newline gets one
+    const size_t room = m_batch.TextCapacity() - m_batch.TextCapacity() / 8 - 1;
+    size_t take = len < room ? len : room;
+    bool add_newline = false;
+    if (take < len || !final) {   // whole lines only
+        const void* nl = memrchr(text, '\n', take);
+        if (!nl) return 0;
+        take = (size_t)(static_cast<const char*>(nl) - text) + 1;
+    } else if (text[take - 1] != '\n') {
+        add_newline = true;
+    }
+    if (take < ((size_t)1 << 20)) return 0;
+    const unsigned threads = m_pool->Width();
+    std::vector<TextCount> counts(threads, TextCount{0, 0});
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(text);
+    uint8_t* dst = m_batch.TextArea();
+    const size_t per = (((take + threads - 1) / threads) + 63) & ~(size_t)63;   // threads * per >= take
+    {
+        timing::Scope ts(timing::PACK);
+        m_pool->Run(threads, [&](unsigned t) {
+            const size_t lo = (size_t)t * per < take ? (size_t)t * per : take, hi = lo + per < take ? lo + per : take;
+            if (hi > lo) counts[t] = CopyAndCountLines(src + lo, hi - lo, dst + lo, lo == 0 || src[lo - 1] == '\n');   // the span starts at a line's start
+        });
+    }
+    uint64_t newlines = 0, empties = 0;
+    for (const auto& c : counts) { newlines += c.newlines; empties += c.empties; }
+    size_t text_bytes = take;
+    if (add_newline) {
+        dst[text_bytes++] = '\n';
+        ++newlines;   // it ends a line that is not empty (the byte before it is not a newline)
+    }
+    const uint64_t strings = newlines - empties, payload = text_bytes - newlines;
+    if (strings > slice.Available() || strings > m_batch.CapacityCount() || (payload + 3 * strings) / 4 > m_batch.CapacityWords())
+        return 0;   // the slice's last strings, or an unusual text: the host packer cuts where it must
+    tally->items += strings;
+    tally->bytes += payload;
+    tally->empties += empties;
+    if (strings > 0) {
+        m_batch.SetText(text_bytes, (size_t)strings, (size_t)payload);
+        slice.Reserve((size_t)strings);
+    }
+    return take;
+}
+
 // Bulk ingest: whole spans of lines are packed straight into the pinned batch
 // (memchr + memcpy per line, no per-line call or temporary), with the same batch/slice
 // hand-offs as Add().
@@ -458,6 +511,22 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
             if (room < cap / 32 || (needs > (double)room && cap - room >= cap / 4)) {
                 const int dev = m_slices.Current().Device();
                 if (!MapCurrent() || !NewBatch(dev)) return (m_ok = false);
+            }
+        }
+        if (m_cfg.device_split && len - pos >= ((size_t)1 << 20)) {
+            // text for the device to split: into an empty batch (what the host packer left in the current one goes out first)
+            if (!m_batch.Empty()) {
+                const int dev = m_slices.Current().Device();
+                if (!MapCurrent() || !NewBatch(dev)) return (m_ok = false);
+            }
+            const size_t took = PushTextForDevice(buf + pos, len - pos, final, tally);
+            if (took) {
+                pos += took;
+                if (!m_batch.Empty()) {
+                    const int dev = m_slices.Current().Device();
+                    if (!MapCurrent() || !NewBatch(dev)) return (m_ok = false);
+                }
+                continue;
             }
         }
         Slice& slice = m_slices.Current();

@@ -42,7 +42,16 @@ public:
             return VKMR_ERR_HIP;
         }
         HipResult r = vkmr_hip_event_record(m.dev, m.begin, copy_stream);
-        {
+        if (batch.TextBytes() > 0) {
+            // raw text: it crosses as it is, the device splits it into the packed layout in the batch's landing zone and
+            // says what it found (checked when the mapping retires)
+            timing::Scope ts(timing::MAP_COPIES);
+            if (r == VKMR_OK) r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceText(), batch.TextArea(), batch.TextBytes());
+            if (r == VKMR_OK)
+                r = vkmr_hip_split_text_async(m.dev, copy_stream, batch.DeviceText(), (uint32_t)batch.TextBytes(), batch.DeviceSplitScratch(), batch.DeviceData(),
+                                              batch.CapacityWords(), batch.DeviceMeta(), (uint32_t)batch.CapacityCount(), batch.DeviceSplitResult());
+            if (r == VKMR_OK) r = vkmr_hip_memcpy_d2h_async(m.dev, copy_stream, batch.HostSplitResult(), batch.DeviceSplitResult(), 3 * sizeof(uint32_t));
+        } else {
             timing::Scope ts(timing::MAP_COPIES);
             if (r == VKMR_OK)
                 r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);
@@ -119,6 +128,20 @@ private:
                 m_spare.emplace_back(it->dev, it->done);
                 it = m_inflight.erase(it);
                 continue;
+            }
+            if (it->batch.TextBytes() > 0) {   // the device's splitter and the host's count must agree, and the strings must have fitted
+                const uint32_t* found = it->batch.HostSplitResult();
+                if (found[0] != it->batch.Count() || found[2] != 0u || found[1] > it->batch.Words()) {
+                    std::cerr << "Mapping for slice #" << it->sub.Number() << " failed: the device split the text into " << found[0] << " string(s) in " << found[1]
+                              << " word(s)" << (found[2] ? ", more than the batch holds" : "") << "; the host counted " << it->batch.Count() << " in at most "
+                              << it->batch.Words() << "." << std::endl;
+                    m_failed = true;
+                    m_spare.emplace_back(it->dev, it->begin);
+                    m_spare.emplace_back(it->dev, it->copied);
+                    m_spare.emplace_back(it->dev, it->done);
+                    it = m_inflight.erase(it);
+                    continue;
+                }
             }
             if (m_verbose) {
                 float ms = 0.f;

@@ -143,6 +143,20 @@ void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, ui
     }
 }
 
+TextCount CopyAndCountLinesPortable(const uint8_t* buf, size_t len, uint8_t* dst, bool after_newline)
+{
+    TextCount c = {0, 0};
+    if (len) memcpy(dst, buf, len);
+    bool prev = after_newline;
+    for (size_t i = 0; i < len; ++i) {
+        const bool nl = buf[i] == '\n';
+        c.newlines += nl;
+        c.empties += nl && prev;
+        prev = nl;
+    }
+    return c;
+}
+
 namespace {
 
 // ---- AVX2 forms: the newlines of 64 input bytes at a time -----------------------------------------------------
@@ -310,6 +324,31 @@ __attribute__((target("avx2"))) void PackIndexedAvx2(const uint8_t* buf, size_t 
     }
 }
 
+// 64 bytes at a time: two vector loads, two stores, the newline mask; an empty line is a newline bit whose lower neighbour
+// (the last bit of the block before, for bit 0) is one too.
+__attribute__((target("avx2,popcnt"))) TextCount CopyAndCountLinesAvx2(const uint8_t* buf, size_t len, uint8_t* dst, bool after_newline)
+{
+    TextCount c = {0, 0};
+    const __m256i nl = _mm256_set1_epi8('\n');
+    uint64_t carry = after_newline ? 1u : 0u;
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(buf + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(buf + i + 32));
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), a);
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+        const uint64_t m = (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, nl)) |
+                           ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, nl)) << 32);
+        c.newlines += (uint64_t)__builtin_popcountll(m);
+        c.empties += (uint64_t)__builtin_popcountll(m & ((m << 1) | carry));
+        carry = m >> 63;
+    }
+    const TextCount t = CopyAndCountLinesPortable(buf + i, len - i, dst + i, carry != 0);
+    c.newlines += t.newlines;
+    c.empties += t.empties;
+    return c;
+}
+
 bool have_avx2()
 {
     static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt") && !getenv("VKMR_NO_AVX2");
@@ -334,6 +373,14 @@ LineCount CountLines(const uint8_t* buf, size_t len)
     if (have_avx2()) return CountLinesAvx2(buf, len);
 #endif
     return CountLinesPortable(buf, len);
+}
+
+TextCount CopyAndCountLines(const uint8_t* buf, size_t len, uint8_t* dst, bool after_newline)
+{
+#ifdef VKMR_HAVE_AVX2_PATH
+    if (have_avx2()) return CopyAndCountLinesAvx2(buf, len, dst, after_newline);
+#endif
+    return CopyAndCountLinesPortable(buf, len, dst, after_newline);
 }
 
 LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix)
@@ -407,6 +454,14 @@ __attribute__((visibility("default"))) int64_t vkmr_host_pack_indexed(const uint
     if (which) vkmr::PackIndexedPortable(buf, len, ix, data, first_word, first_word + c.words, meta);
     else vkmr::PackIndexed(buf, len, ix, data, first_word, first_word + c.words, meta);
     return (int64_t)c.strings;
+}
+
+// CopyAndCountLines on one buffer: out[0..1] = newlines, empties; which as above.
+__attribute__((visibility("default"))) void vkmr_host_copy_and_count(const uint8_t* buf, uint64_t len, uint8_t* dst, int after_newline, int which, uint64_t* out)
+{
+    const vkmr::TextCount c = which ? vkmr::CopyAndCountLinesPortable(buf, len, dst, after_newline != 0) : vkmr::CopyAndCountLines(buf, len, dst, after_newline != 0);
+    out[0] = c.newlines;
+    out[1] = c.empties;
 }
 
 // A prefix split with capacity limits and `final` unset, as the stream processor calls it: out[0..4] = consumed, strings,

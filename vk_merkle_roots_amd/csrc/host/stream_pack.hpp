@@ -59,6 +59,13 @@ LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix);
 void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
                          vkmr_metadata* meta, uint16_t* sizes = nullptr);
 
+// One pass for the device-side splitter (vkmr_hip_split_text_async): buf[0,len) is copied to dst as it is, and its lines
+// are counted -- newlines, and those among them that end an EMPTY line (the byte before them is a newline too;
+// `after_newline` says whether the byte before buf[0] was one, true at the start of a stream).  Strings = newlines - empties.
+struct TextCount { uint64_t newlines, empties; };
+TextCount CopyAndCountLines(const uint8_t* buf, size_t len, uint8_t* dst, bool after_newline);
+TextCount CopyAndCountLinesPortable(const uint8_t* buf, size_t len, uint8_t* dst, bool after_newline);
+
 // The portable forms (one memchr per line).  PackLines / CountLines use AVX2 forms where the CPU has them (the newline
 // positions of 64 input bytes at a time); these stay as the reference the tests compare them with.
 PackResult PackLinesPortable(const uint8_t* buf, size_t len, bool final, uint32_t* data, uint64_t first_word,
