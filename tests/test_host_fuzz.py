@@ -130,7 +130,7 @@ def test_indexed_two_pass_packer_equals_the_portable_one(native, parts, first_wo
     h.vkmr_host_pack_prefix(ptr, len(stream), 1, ref_data.ctypes.data, first_word, first_word + cap_words, ref_meta.ctypes.data, cap_meta, 1, ref.ctypes.data)
     consumed, strings, words, nbytes, empties = (int(v) for v in ref)
     assert consumed == len(stream)
-    for which in (0, 1):
+    for which in (0, 1, 2):      # the vector form, the portable one, the vector form with streaming stores
         data = np.full(first_word + cap_words + 8, 0xABABABAB, dtype=np.uint32)
         meta = np.zeros((cap_meta + 1, 2), dtype=np.uint32)
         out = np.zeros(4, np.uint64)

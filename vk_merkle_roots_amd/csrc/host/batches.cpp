@@ -1,6 +1,7 @@
 // batches.cpp -- see batches.hpp.
 #include "batches.hpp"
 
+#include <chrono>
 #include <cstring>
 #include <iostream>
 #include <thread>
@@ -216,13 +217,16 @@ PackResult Batch::PushLinesParallel(const char* buf, size_t len, bool final, siz
         strings += c.strings;
     }
     if (k == 0) return r;
-    // 4. pack them at their prefix offsets, each within its own words
+    // 4. pack them at their prefix offsets, each within its own words; with ordinary or streaming stores, as the pool's tuner says
     {
         timing::Scope ts(timing::PACK);
+        const bool streaming = m_owner ? m_owner->Tuner().Next() : false;
+        const auto t0 = std::chrono::steady_clock::now();
         pool.Run((unsigned)k, [&](unsigned t) {
             PackIndexed(b + parts[t].lo, parts[t].hi - parts[t].lo, index[t], m_data, w0[t], w0[t] + parts[t].c.words, m_meta + c0[t],
-                        m_sizes ? m_sizes + c0[t] : nullptr);
+                        m_sizes ? m_sizes + c0[t] : nullptr, streaming);
         });
+        if (m_owner) m_owner->Tuner().Report(streaming, words * 4, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     for (size_t t = 0; t < k; ++t) {
         r.bytes += parts[t].c.bytes;
@@ -247,8 +251,8 @@ void Batch::Pop(size_t count)
     }
 }
 
-Batches::Batches(int dev, size_t data_bytes, bool device_split)
-    : m_dev(dev), m_device_split(device_split), m_words(data_bytes / 4), m_count(data_bytes / sizeof(vkmr_digest)), m_live(0), m_next(0)
+Batches::Batches(int dev, size_t data_bytes, bool device_split, int pack_stream)
+    : m_dev(dev), m_device_split(device_split), m_tuner(pack_stream), m_words(data_bytes / 4), m_count(data_bytes / sizeof(vkmr_digest)), m_live(0), m_next(0)
 {
     if (m_words > 0xFFFFFFFFull) m_words = 0xFFFFFFFFull;   // vkmr_metadata::start is a 32-bit word index
     if (m_count == 0) m_count = 1;

@@ -127,13 +127,46 @@ private:
     number_type m_number = 0xFFFFFFFFu;
 };
 
+// Which form of the packer's second pass a pool's batches use: ordinary stores leave the packed words in the cache, where
+// the copy engine finds them on a quiet host; streaming stores save the read-for-ownership of every destination line,
+// which is what counts when the host's memory is busy (profiles/r03_frontend_streaming_stores.txt: either can be 20-30 %
+// faster than the other).  The tuner times both -- alternately at first, then the slower one every sixteenth call -- and
+// hands out the form that has been moving more bytes per second of late.
+class PackTuner {
+public:
+    explicit PackTuner(int forced = -1) : m_forced(forced) {}
+    bool Next()   // true: streaming stores for this call
+    {
+        if (m_forced >= 0) return m_forced != 0;
+        const unsigned k = m_calls++;
+        if (k < 8) return (k & 1u) != 0;                       // four calls each to begin with
+        const bool better = m_rate[1] > m_rate[0];             // bytes per second, smoothed
+        return (k % 16u == 15u) ? !better : better;            // the other form now and then: the host's state changes
+    }
+    void Report(bool streaming, size_t bytes, double seconds)
+    {
+        if (bytes == 0 || seconds <= 0.0) return;
+        const double rate = (double)bytes / seconds;
+        double& r = m_rate[streaming ? 1 : 0];
+        r = r == 0.0 ? rate : 0.75 * r + 0.25 * rate;
+    }
+    double Rate(bool streaming) const { return m_rate[streaming ? 1 : 0]; }
+
+private:
+    int m_forced;
+    unsigned m_calls = 0;
+    double m_rate[2] = {0.0, 0.0};
+};
+
 // Allocates and recycles batches for one device.
 class Batches {
 public:
     // data_bytes: capacity of a batch's data buffer; metadata capacity follows the
     // reference's ratio (one entry per 32 data bytes, src/vkmr/Batches.h:131-134).
     // device_split: every batch also gets what vkmr_hip_split_text_async needs (a text area in HBM, scratch, result words)
-    Batches(int dev, size_t data_bytes, bool device_split = false);
+    // pack_stream: -1 the tuner decides between ordinary and streaming stores in the packer, 0 / 1 forces one
+    Batches(int dev, size_t data_bytes, bool device_split = false, int pack_stream = -1);
+    PackTuner& Tuner() { return m_tuner; }
     ~Batches();
     Batches(const Batches&) = delete;
     Batches& operator=(const Batches&) = delete;
@@ -160,6 +193,7 @@ private:
     void JoinPrefetch();
     int m_dev;
     bool m_device_split = false;
+    PackTuner m_tuner;
     size_t m_words, m_count, m_live, m_allocations = 0;
     uint32_t m_next;
     std::vector<Buffers> m_free;

@@ -34,6 +34,7 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_PROOF_INDEX")) c.proof_index = atoll(e);
     if (const char* e = getenv("VKMR_SEND_METADATA")) c.send_sizes = atoi(e) == 0;
     if (const char* e = getenv("VKMR_DEVICE_SPLIT")) c.device_split = atoi(e) != 0;
+    if (const char* e = getenv("VKMR_PACK_STREAM")) c.pack_stream = atoi(e) < 0 ? -1 : (atoi(e) != 0);
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -120,7 +121,7 @@ HipSha256D::Instance::Instance(const std::string& name, std::vector<int> devices
             const uint64_t need = ((cfg.expected_input_bytes + cfg.expected_input_bytes / 4 + (1u << 16)) + ((1u << 20) - 1)) & ~(uint64_t)((1u << 20) - 1);
             if (need < batch_bytes) batch_bytes = (size_t)need;
         }
-        pd.batches.reset(new Batches(d, batch_bytes, cfg.device_split));
+        pd.batches.reset(new Batches(d, batch_bytes, cfg.device_split, cfg.pack_stream));
         if (cfg.verbose) {
             char devname[256] = "";
             size_t free_b = 0, total_b = 0;

@@ -43,13 +43,14 @@ struct HipConfig {
                                      // 0.20 s with 16 on 2^25 strings, profiles/r02_end_to_end_stdin.txt)
     bool send_sizes = true;          // batches of strings shorter than 65 536 bytes cross PCIe as data + 2 bytes per string; the {start, size}
                                      // entries are written on the device (VKMR_SEND_METADATA=1 sends the 8-byte entries instead, as the reference does)
+    int pack_stream = -1;            // the packer's stores: -1 tuned at run time (ordinary vs streaming, PackTuner), 0 / 1 forced (VKMR_PACK_STREAM)
     bool device_split = false;       // VKMR_DEVICE_SPLIT=1: large spans of text cross PCIe as they are and are split into strings on the device
                                      // (vkmr_hip_split_text_async); the host copies them into pinned memory and counts their lines, nothing else.
                                      // Spans that do not qualify (short, or more strings than the slice has room for) take the host packer
     long long proof_index = -1;      // >= 0: also produce the Merkle proof of that leaf (0-based, stream order; README.md:118-120)
     bool verbose = false;            // per-op log lines like the reference prints
     static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_BATCH_MAX_MB, VKMR_MAX_INFLIGHT,
-                                     // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_SEND_METADATA, VKMR_DEVICE_SPLIT, VKMR_PROOF_INDEX, VKMR_VERBOSE
+                                     // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_SEND_METADATA, VKMR_PACK_STREAM, VKMR_DEVICE_SPLIT, VKMR_PROOF_INDEX, VKMR_VERBOSE
 };
 
 class HipSha256D {

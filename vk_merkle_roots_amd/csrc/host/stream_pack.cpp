@@ -349,6 +349,103 @@ __attribute__((target("avx2,popcnt"))) TextCount CopyAndCountLinesAvx2(const uin
     return c;
 }
 
+// [done, upto) of the destination from the window whose first byte is destination byte `lo` (a multiple of 64): ordinary
+// stores up to the first line boundary and for the last, partial, line; streaming stores for the whole lines between.
+__attribute__((target("avx2"))) uint64_t stream_out(uint8_t* dst, const uint8_t* win, uint64_t lo, uint64_t done, uint64_t upto)
+{
+    if (upto <= done) return done;
+    uint64_t a = done;
+    const uint64_t head_end = (a + 63u) & ~(uint64_t)63;
+    if (a < head_end) {
+        const uint64_t e = head_end < upto ? head_end : upto;
+        memcpy(dst + a, win + (a - lo), (size_t)(e - a));
+        a = e;
+    }
+    for (; a + 64u <= upto; a += 64u) {
+        const __m256i x = _mm256_load_si256(reinterpret_cast<const __m256i*>(win + (a - lo)));
+        const __m256i y = _mm256_load_si256(reinterpret_cast<const __m256i*>(win + (a - lo) + 32));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + a), x);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + a + 32), y);
+    }
+    if (a < upto) memcpy(dst + a, win + (a - lo), (size_t)(upto - a));
+    return upto;
+}
+
+// Pass 2 with non-temporal stores.  The destination is written once and read next by the copy engine, so a core that
+// brings every destination line into its cache first (read for ownership) moves a third more memory than it has to --
+// unless the batch then stays in the last-level cache and the copy engine reads it there, which is what happens on a quiet
+// host and not on a busy one (profiles/r03_frontend_streaming_stores.txt): the caller tries both and keeps the faster
+// (PackTuner).  The lines are assembled in a small window on the stack -- where the four-vector copy may run past a
+// line's end freely -- and the window's completed 64-byte lines go to the destination with streaming stores; the part's
+// first and last, partial, lines are written the ordinary way (their other bytes are another thread's).
+__attribute__((target("avx2"))) void PackIndexedAvx2Stream(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word,
+                                                           uint64_t end_word, vkmr_metadata* meta, uint16_t* sizes)
+{
+    (void)end_word;
+    constexpr size_t WIN = 8192;
+    alignas(64) uint8_t win[WIN + 256];
+    // destination offsets are counted from a 64-byte-aligned address at or below `data` (streaming stores need aligned lines)
+    const uint64_t skew = reinterpret_cast<uintptr_t>(data) & 63u;
+    uint8_t* const dst = reinterpret_cast<uint8_t*>(data) - skew;
+    const uint64_t first_b = first_word * 4u + skew;
+    uint64_t lo = first_b & ~(uint64_t)63;   // destination offset of win[0]
+    uint64_t done = first_b;                 // destination bytes below this are written
+    uint64_t w = first_word;
+    vkmr_metadata* mo = meta;
+    uint16_t scrap;
+    uint16_t* so = sizes ? sizes : &scrap;
+    const size_t so_step = sizes ? 1 : 0;
+    uint32_t start = 0;
+    const uint32_t* ends = ix.ends;
+    for (size_t i = 0; i < ix.count; ++i) {
+        const uint32_t e = ends[i];
+        const uint32_t n = e - start;
+        if (n) {
+            const uint32_t nw = (n + 3u) >> 2;
+            mo->start = (uint32_t)w;
+            mo->size = n;
+            ++mo;
+            *so = (uint16_t)(n < 0xFFFFu ? n : 0xFFFFu);
+            so += so_step;
+            const uint64_t pos = w * 4u + skew;
+            const uint8_t* src = buf + start;
+            if (n <= 128u && (size_t)start + 128u <= len) {
+                if (pos + 128u > lo + WIN) {   // the window is full: its whole lines go out, what is left of the current line moves to the front
+                    const uint64_t keep = pos & ~(uint64_t)63;
+                    done = stream_out(dst, win, lo, done, keep < done ? done : keep);
+                    if (keep > lo) {
+                        memmove(win, win + (keep - lo), (size_t)(pos - keep));
+                        lo = keep;
+                    }
+                }
+                uint8_t* d = win + (pos - lo);
+                const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src));
+                const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32));
+                const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 64));
+                const __m256i dd = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 96));
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(d), a);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(d + 32), b);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(d + 64), c);
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(d + 96), dd);
+                uint32_t last;
+                memcpy(&last, d + 4u * (nw - 1u), 4);
+                last &= 0xFFFFFFFFu >> (8u * ((0u - n) & 3u));
+                memcpy(d + 4u * (nw - 1u), &last, 4);
+            } else {   // a long line, or one of the part's last: the window goes out, the line is copied directly
+                done = stream_out(dst, win, lo, done, pos);
+                data[w + nw - 1] = 0u;
+                memcpy(dst + pos, src, n);
+                done = pos + 4u * (uint64_t)nw;
+                lo = done & ~(uint64_t)63;
+            }
+            w += nw;
+        }
+        start = e + 1u;
+    }
+    done = stream_out(dst, win, lo, done, w * 4u + skew);
+    _mm_sfence();
+}
+
 bool have_avx2()
 {
     static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt") && !getenv("VKMR_NO_AVX2");
@@ -392,10 +489,12 @@ LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix)
 }
 
 void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word, vkmr_metadata* meta,
-                 uint16_t* sizes)
+                 uint16_t* sizes, bool streaming)
 {
 #ifdef VKMR_HAVE_AVX2_PATH
-    if (have_avx2()) return PackIndexedAvx2(buf, len, ix, data, first_word, end_word, meta, sizes);
+    if (have_avx2())
+        return streaming ? PackIndexedAvx2Stream(buf, len, ix, data, first_word, end_word, meta, sizes)
+                         : PackIndexedAvx2(buf, len, ix, data, first_word, end_word, meta, sizes);
 #endif
     PackIndexedPortable(buf, len, ix, data, first_word, end_word, meta, sizes);
 }
@@ -448,11 +547,11 @@ __attribute__((visibility("default"))) int64_t vkmr_host_pack_indexed(const uint
 {
     if (len >= 0xFFFFFF00ull) return -1;
     vkmr::LineIndex ix;
-    const vkmr::LineCount c = which ? vkmr::IndexLinesPortable(buf, len, &ix) : vkmr::IndexLines(buf, len, &ix);
+    const vkmr::LineCount c = which == 1 ? vkmr::IndexLinesPortable(buf, len, &ix) : vkmr::IndexLines(buf, len, &ix);
     if (out) { out[0] = c.words; out[1] = c.bytes; out[2] = c.empties; out[3] = ix.count; }
     if (!ix.ends || first_word + c.words > data_capacity_words || c.strings > meta_capacity) return -1;
-    if (which) vkmr::PackIndexedPortable(buf, len, ix, data, first_word, first_word + c.words, meta);
-    else vkmr::PackIndexed(buf, len, ix, data, first_word, first_word + c.words, meta);
+    if (which == 1) vkmr::PackIndexedPortable(buf, len, ix, data, first_word, first_word + c.words, meta);
+    else vkmr::PackIndexed(buf, len, ix, data, first_word, first_word + c.words, meta, nullptr, which == 2);   // 2: the streaming-store form
     return (int64_t)c.strings;
 }
 

@@ -53,8 +53,10 @@ struct LineIndex {
     void Reserve(size_t lines);   // room for `lines` entries plus the slack the vector form writes past the end; contents are dropped
 };
 LineCount IndexLines(const uint8_t* buf, size_t len, LineIndex* ix);
+// streaming: the packed words go out with non-temporal stores (same words; which is faster depends on how busy the host's
+// memory is: Batches' PackTuner tries both).
 void PackIndexed(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
-                 vkmr_metadata* meta, uint16_t* sizes = nullptr);
+                 vkmr_metadata* meta, uint16_t* sizes = nullptr, bool streaming = false);
 LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix);
 void PackIndexedPortable(const uint8_t* buf, size_t len, const LineIndex& ix, uint32_t* data, uint64_t first_word, uint64_t end_word,
                          vkmr_metadata* meta, uint16_t* sizes = nullptr);
