@@ -161,3 +161,28 @@ def test_copy_and_count_lines(native, parts, after_newline):
         h.vkmr_host_copy_and_count(buf.ctypes.data if len(stream) else None, len(stream), dst.ctypes.data, int(after_newline), which, out.ctypes.data)
         assert [int(v) for v in out] == [want_nl, want_empty]
         assert dst[:len(stream)].tobytes() == stream and (dst[len(stream):] == 0xEE).all()
+
+
+def test_streaming_store_form_of_the_packer_on_large_parts(native):
+    """PackIndexed with streaming stores assembles lines in an 8 KiB window and sends whole 64-byte lines out: parts much
+    larger than the window, lines longer than its 128-byte fast path, destinations at every word offset within a line
+    (the part's first and last lines are shared with other parts) -- same words, same entries, nothing outside."""
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    rng = np.random.default_rng(5)
+    for hi, count in ((127, 30000), (300, 8000), (3, 50000), (5000, 300)):
+        stream = b"".join(rng.integers(33, 126, size=int(k), dtype=np.uint8).tobytes() + b"\n" for k in rng.integers(0, hi + 1, size=count))
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        cap_meta = stream.count(b"\n") + 1
+        cap_words = len(stream) // 4 + cap_meta + 1
+        for first_word in (0, 1, 7, 15, 16, 33):
+            outs = []
+            for which in (1, 2):
+                data = np.full(first_word + cap_words + 40, 0xABABABAB, dtype=np.uint32)
+                meta = np.zeros((cap_meta + 1, 2), dtype=np.uint32)
+                out = np.zeros(4, np.uint64)
+                got = h.vkmr_host_pack_indexed(buf.ctypes.data, len(stream), data.ctypes.data, first_word, first_word + cap_words, meta.ctypes.data, cap_meta, which,
+                                               out.ctypes.data)
+                outs.append((got, out.tolist(), data, meta))
+            assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+            assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3]), (hi, first_word)
