@@ -93,3 +93,16 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300, env=env)
     assert r.returncode != 0 and r.stdout.strip() == b""
+
+
+def test_pack_tuner_picks_the_faster_form(tmp_path):
+    """PackTuner: alternates at first, then uses the form of the packer's second pass (ordinary or streaming stores) that has
+    moved more bytes per second of late, probing the other every sixteenth call; follows a change of the host's state;
+    can be forced (tests/c/pack_tuner_test.cpp)."""
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(ROOT, "vk_merkle_roots_amd", "csrc", "host")
+    exe = str(tmp_path / "pack_tuner_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I", host, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "pack_tuner_test.cpp"), "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout.strip() == b"ok", (r.stdout, r.stderr)

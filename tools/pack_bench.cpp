@@ -7,6 +7,7 @@
 //                                                                      of the mapping inside the timed passes); 2: mapped, every span
 //                                                                      populated with madvise(MADV_POPULATE_READ) before it is indexed;
 //                                                                      3: the same on a helper thread, one span ahead
+//   tools/pack_bench file threads span resident 1                    pass 2 with streaming stores
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -37,6 +38,7 @@ int main(int argc, char** argv)
     const size_t len = (size_t)st.st_size;
     const int mode = argc > 4 ? atoi(argv[4]) : 0;
     const bool resident = mode == 1;
+    const bool streaming = argc > 5 && atoi(argv[5]) != 0;
     std::vector<uint8_t> copy;
     if (resident) {
         copy.resize(len);
@@ -108,7 +110,7 @@ int main(int argc, char** argv)
                 size_t w = 0, n = 0;
                 for (size_t t = 0; t < parts.size(); ++t) { w0[t] = w; c0[t] = n; w += parts[t].c.words; n += parts[t].c.strings; }
                 if (w > data.size() || n > meta.size()) { printf("span does not fit\n"); return 1; }
-                if (form == 0) pool.Run((unsigned)parts.size(), [&](unsigned t) { PackIndexed(b + at + parts[t].lo, parts[t].hi - parts[t].lo, index[t], data.data(), w0[t], w0[t] + parts[t].c.words, meta.data() + c0[t]); });
+                if (form == 0) pool.Run((unsigned)parts.size(), [&](unsigned t) { PackIndexed(b + at + parts[t].lo, parts[t].hi - parts[t].lo, index[t], data.data(), w0[t], w0[t] + parts[t].c.words, meta.data() + c0[t], nullptr, streaming); });
                 else pool.Run((unsigned)parts.size(), [&](unsigned t) { PackLines(b + at + parts[t].lo, parts[t].hi - parts[t].lo, true, data.data(), w0[t], data.size(), meta.data() + c0[t], parts[t].c.strings); });
                 const double d = now();
                 t1 += c - a;
@@ -119,7 +121,7 @@ int main(int argc, char** argv)
             if (ahead.joinable()) ahead.join();
             const double total = now() - t0;
             printf("%s, %s, %u threads, spans of %zu MiB: %.1f ms = %.1f GB/s (%zu lines; pass 1 %.1f ms, pass 2 %.1f ms; %.2f + %.2f ns per line and thread)%s\n",
-                   resident ? "resident" : mode == 2 ? "mapped+populate" : mode == 3 ? "mapped+populate ahead" : "mapped", form == 0 ? "index + pack-indexed" : "count + pack (per-line walk)", T, span >> 20, total * 1e3, (double)len / total / 1e9, lines, t1 * 1e3, t2 * 1e3,
+                   resident ? "resident" : mode == 2 ? "mapped+populate" : mode == 3 ? "mapped+populate ahead" : "mapped", form == 0 ? (streaming ? "index + pack-indexed (streaming stores)" : "index + pack-indexed") : "count + pack (per-line walk)", T, span >> 20, total * 1e3, (double)len / total / 1e9, lines, t1 * 1e3, t2 * 1e3,
                    t1 / (double)lines * 1e9 * T, t2 / (double)lines * 1e9 * T, mode >= 2 ? (" populate wait " + std::to_string(t3 * 1e3) + " ms").c_str() : "");
             if (!resident) munmap(const_cast<uint8_t*>(b), len);
         }
