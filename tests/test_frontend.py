@@ -68,6 +68,20 @@ def test_empty_input_prints_no_root(native):
     assert m is None and r.stderr.count(b"Read an empty string?") == 3
 
 
+def test_a_read_error_is_not_the_end_of_the_stream(native):
+    """a read(2) that FAILS (EISDIR here: stdin is a directory; EIO on a dying disk) used to be taken for the end
+    of the stream -- a root over whatever had arrived, exit code 0.  Now: the error on stderr, no root, exit code 2."""
+    fd = os.open("/tmp", os.O_RDONLY)
+    try:
+        r = subprocess.run([tool(native, "vkmr"), "CPU"], stdin=fd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    finally:
+        os.close(fd)
+    assert r.returncode == 2 and b"computed root" not in r.stdout and b"Reading the input failed" in r.stderr, (r.returncode, r.stderr)
+    # an ordinary stream right behind it is unaffected
+    r, out, m = run_vkmr(native, "CPU", b"a\nb\n")
+    assert r.returncode == 0 and m and m["items"] == "2"
+
+
 def test_unknown_backend_aborts(native):
     r, out, m = run_vkmr(native, "no-such-device", b"a\n")
     assert r.returncode == 1 and b"No device selected; aborting." in r.stderr

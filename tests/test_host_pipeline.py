@@ -428,3 +428,53 @@ print(json.dumps([res, text]))
         body = t if variant == "as written" else b"\n\n" + t[:-1].replace(b"\n", b"\r\n\n", 1)
         want, cnt, nb = oracle.root_of_stream(body)
         assert (rc, root, items, nbytes) == (0, want, cnt, nb), (seed, n, maxlen, variant, rc, root, want)
+
+
+def test_packed_pipeline_that_runs_out_of_slices_gives_up_cleanly(native, oracle, tmp_path):
+    """vkmr_host_pipeline_packed stages every batch before it maps the first.  When staging fails half way
+    (no device memory for the next slice) the instance still holds staged batches, each with a raw pointer into its
+    pool: they must be released before the pools, not by the vector's destructor after them.  And with slice_log2 = 0
+    the slice budget must follow the size the instance picks from the device's memory, not the 2^23 the caller guessed.
+    The stream processor + entry point under ASan/UBSan against the fake ABI with an HBM cap."""
+    import numpy as np
+    import vk_merkle_roots_amd as vk
+    from vk_merkle_roots_amd.engine import digest_hex
+    out = os.path.join(ROOT, "tests", "_build", "fake")
+    os.makedirs(out, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", CSRC]
+    lib = os.path.join(out, "libvkmr_hip.so")
+    lib_src = [os.path.join(ROOT, "tests", "c", "fake_vkmr_hip.cpp"), os.path.join(HOST, "cpu_sha256d.cpp")]
+    if not os.path.exists(lib):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-shared", "-fPIC"] + SAN + inc + lib_src + ["-o", lib])
+    files = ["packed_pipeline.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "batches.cpp", "slices.cpp", "mappings.cpp", "reductions.cpp", "stream_pack.cpp"]
+    exe = os.path.join(out, "packed_pipeline_client_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-pthread"] + SAN + inc + [os.path.join(ROOT, "tests", "c", "packed_pipeline_client.cpp")] +
+                          [os.path.join(HOST, f) for f in files] + ["-o", exe, "-L", out, "-lvkmr_hip", "-Wl,-rpath," + out])
+    b = vk.rndm_packed(21, 60000, 127)
+    want = digest_hex(oracle.root(oracle.leaves_packed(b.data, b.meta)))
+    dpath, mpath = str(tmp_path / "data.u32"), str(tmp_path / "meta.u32")
+    np.ascontiguousarray(b.data).tofile(dpath)
+    np.ascontiguousarray(b.meta).tofile(mpath)
+    base = {k: v for k, v in os.environ.items() if not k.startswith("VKMR_") and k != "LD_PRELOAD"}
+    base.update(LD_LIBRARY_PATH=out, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", VKMR_BATCH_MAX_MB="0")
+
+    def client(per_batch, slice_log2, **knobs):
+        r = subprocess.run([exe, dpath, mpath, str(per_batch), str(slice_log2)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(base, **{k: str(v) for k, v in knobs.items()}), timeout=300)
+        assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr and b"LeakSanitizer" not in r.stderr, r.stderr[-3000:].decode()
+        assert r.returncode == 0, r.stderr[-2000:].decode()
+        line = r.stdout.decode().strip().splitlines()[-1]
+        return line, r.stderr.decode()
+
+    # plenty of memory: the golden root, with a given slice size and with the instance's own choice
+    assert client(4000, 12)[0] == "rc=0 root=" + want
+    assert client(4000, 0)[0] == "rc=0 root=" + want
+    # 2.2 MB of "HBM": slices of 2^10 x 32 B; the batches' landing zones take most of it, the 59 slices the strings fill do not fit --
+    # staging stops with batches staged, the call fails, nothing is used after it was freed
+    line, err = client(4000, 10, VKMR_FAKE_HBM_BYTES=2200000)
+    assert line == "rc=-1 root=" and "Failed to allocate" in err, (line, err[-500:])
+    # 10 MB and no slice size given: the instance clamps the slice to what fits (2^12 digests: 15 slices) and sizes the budget
+    # for THAT size -- the root is the golden one (before: a budget for 2^23-digest slices, "slice budget used up and nothing
+    # in flight")
+    line, err = client(4000, 0, VKMR_FAKE_HBM_BYTES=10000000)
+    assert line == "rc=0 root=" + want, (line, err[-800:])

@@ -85,12 +85,24 @@ def sustained(dev, launch, seconds, hw):
     return dt / n * 1e3, med(pw), med(sk)
 
 
-def read_stamps(L, tag):
-    buf = np.empty(SLOTS * 8, dtype=np.uint64)
-    buf.fill(0)   # touched pages: a GPU copy into never-written calloc pages faults ("write access to a read-only page")
-    assert L.vkmr_hip_debug_stamps(C.c_void_p(buf.ctypes.data), SLOTS * 8) == 0
-    s = buf.reshape(SLOTS, 8)
-    s = s[(s[:, 6] == tag) & (s[:, 5] > s[:, 1])]
+_PINNED = {}
+
+
+def pinned_u64(lib, words):
+    """A pinned host array for the stamp read-back (the ABI's own allocator): the copy is a plain DMA into pages the
+    driver already maps, whatever the runtime would do for pageable memory of this size."""
+    if words not in _PINNED:
+        p = C.c_void_p()
+        assert lib.vkmr_hip_host_alloc(C.c_size_t(8 * words), C.byref(p)) == 0
+        _PINNED[words] = (p, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(words,)))
+    return _PINNED[words]
+
+
+def read_stamps(L, lib, tag):
+    p, view = pinned_u64(lib, SLOTS * 8)
+    assert L.vkmr_hip_debug_stamps(p, SLOTS * 8) == 0
+    s = view.copy().reshape(SLOTS, 8)
+    s = s[((s[:, 6] & np.uint64(0xFFFFFF)) == tag) & (s[:, 5] > s[:, 1])]
     if len(s):
         s = s[s[:, 7] == s[:, 7].max()]      # the widest launch of that kernel (bulk pass 0), not the later, smaller ones
     return s.astype(np.float64)
@@ -110,6 +122,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--settle", type=int, default=12, help="launches between the stamp buffer's clearing and the launch whose stamps are read")
     a = ap.parse_args()
     dev = vk.HipDevice(0)
     L = C.CDLL(STAMPS_LIB)
@@ -126,6 +139,13 @@ def main():
     d_data, d_meta, d_out = dev.upload(b.data), dev.upload(b.meta), dev.alloc(32 * b.count)
     d_scr, d_root = dev.reduce_scratch(b.count), dev.alloc(32)
     height = vk.tree_height(b.count)
+    # every device range this tool's kernels may touch, on stderr BEFORE the first launch: a memory access fault names an
+    # address and nothing else (profiles/r04_kernel_clock_fault.txt)
+    for name, buf in (("data", d_data), ("meta", d_meta), ("digests", d_out), ("reduce scratch", d_scr), ("root", d_root)):
+        sys.stderr.write("[kernel_clock] %-14s 0x%012x .. 0x%012x (%d bytes)\n" % (name, buf.ptr, buf.ptr + buf.nbytes, buf.nbytes))
+    sp, _ = pinned_u64(dev.lib, SLOTS * 8)
+    sys.stderr.write("[kernel_clock] %-14s 0x%012x .. 0x%012x (pinned host)\n" % ("stamp copy", sp.value, sp.value + SLOTS * 64))
+    sys.stderr.flush()
     out = {"workload": f"rndm {a.seed} 2^{a.leaves_log2} {a.maxlen}", "library": os.path.relpath(STAMPS_LIB, ROOT),
            "method": "per-workgroup d(s_memtime)/d(s_memrealtime) x 100 MHz after >= %.1f s of back-to-back launches" % a.seconds,
            "power_cap_W": Hwmon.read(hw.cap, 1e6), "hwmon": hw.base}
@@ -133,14 +153,22 @@ def main():
 
     def one(name, tag, launch):
         ms_sus, pw, sk = sustained(dev, launch, a.seconds, hw)
-        L.vkmr_hip_debug_stamps(None, 0)   # clear
+        L.vkmr_hip_debug_stamps(None, 0)   # clear (a device-wide wait on either side: the chip idles for a moment)
+        # The stamps that are read are those of the LAST of several back-to-back launches (each overwrites the one before): the
+        # first launch after the pause runs on a clock that is still ramping (2^26: 6.5 ms against 5.3 sustained, 1.69 GHz
+        # against 2.0 -- profiles/r04_kernel_clock_fault.txt)
+        for _ in range(a.settle):
+            launch()
         dev.record(e0); launch(); dev.record(e1); dev.sync()
-        s = read_stamps(L, tag)
+        s = read_stamps(L, dev.lib, tag)
         rec = clock_of(s)
         rec.update(ms_per_launch_sustained=round(ms_sus, 4), ms_stamped_launch=round(dev.elapsed_ms(e0, e1), 4),
                    board_power_W=pw, sclk_sysfs_MHz=sk, kernel=dev.lib.vkmr_hip_kernel_info().decode().split(" reduce=")[0] if tag == 0x4d4150 else "reduce_pass_kernel (first bulk pass)")
         if tag == 0x4d4150 and len(s):   # phases of a map workgroup's first wavefront
             life = s[:, 4] - s[:, 0]
+            wait = (s[:, 6].astype(np.uint64) >> np.uint64(24)).astype(np.float64)   # persistent form: cycles at the tile-done barrier
+            if wait.max() > 0:
+                rec["barrier_wait_share"] = round(float(np.median(wait / life)), 4)
             rec["phase_share"] = {"sort": round(float(np.median((s[:, 2] - s[:, 0]) / life)), 4),
                                   "stage": round(float(np.median((s[:, 3] - s[:, 2]) / life)), 4),
                                   "hash": round(float(np.median((s[:, 4] - s[:, 3]) / life)), 4)}

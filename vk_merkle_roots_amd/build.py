@@ -108,6 +108,19 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     if prio_gap is None:
         _run([_hipcc()] + common + ["-shared", "-Wl,-rpath,/opt/rocm/lib", "-o", target, src])
         return target
+    try:
+        for tool in ("clang", "lld", "clang-offload-bundler"):
+            _llvm(tool)
+    except RuntimeError as e:
+        # the issue pass needs the llvm tools beside hipcc: without them the library is still built -- the plain one-step way,
+        # under a build id of its own (no pass: 25 % slower kernels, no static counts) -- and says so
+        sys.stderr.write(f"[build] WARNING: {e}; building {os.path.basename(target)} WITHOUT the issue-priority pass\n")
+        common = [c for c in common if not c.startswith("-DVKMR_BUILD_ID=")] + [f'-DVKMR_BUILD_ID="{source_id(defines, None, split_every)}"']
+        _run([_hipcc()] + common + ["-shared", "-Wl,-rpath,/opt/rocm/lib", "-o", target, src])
+        isa = os.path.splitext(target)[0] + ".isa.json"
+        if os.path.exists(isa):
+            os.remove(isa)          # counts of another build must not sit beside this one
+        return target
     work = os.path.join(ROOT, "build", "obj", os.path.basename(target))
     os.makedirs(work, exist_ok=True)
     dev_s, prio_s = os.path.join(work, "device.s"), os.path.join(work, "device_prio.s")
@@ -119,6 +132,15 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     out, stats = isa_prio_pass.transform(lines, prio_gap, prio_level, split_every, LATENCY_BOUND_KERNELS, rotate_level)
     with open(prio_s, "w") as f:
         f.writelines(out)
+    # the pass rewrites compiler output with regular expressions: check that it did what it says and nothing else, and that
+    # every opcode the static counts will price is one the issue measurements covered, BEFORE anything is assembled
+    diffs = isa_prio_pass.verify(lines, out)
+    if diffs:
+        raise RuntimeError("isa_prio_pass changed more than s_setprio insertions and add3 splits:\n  " + "\n  ".join(diffs))
+    audit = isa_prio_pass.audit(out)
+    if audit["unclassified"] or audit["block_count_errors"]:
+        sys.stderr.write("[build] WARNING: the issue model does not cover this listing (tests/test_isa_prio_pass.py will fail):\n  " +
+                         "\n  ".join(audit["unclassified"] + audit["block_count_errors"]) + "\n")
     _run([_llvm("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", prio_s, "-o", dev_o])
     _run([_llvm("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_co, dev_o])
     _run([_llvm("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
@@ -130,7 +152,8 @@ def _build_hip_variant(target, defines, force, prio_gap=PRIO_GAP, prio_level=1, 
     # static instruction counts of the hash blocks, for bench.py's issue roofline; travels with the library
     import json
     info = {"build": source_id(defines, prio_gap, split_every), "library": os.path.basename(target), "prio_gap": prio_gap,
-            "split_add3_every": split_every, "pass": stats, "hash_blocks": isa_prio_pass.hash_blocks(out)}
+            "split_add3_every": split_every, "pass": stats, "hash_blocks": isa_prio_pass.hash_blocks(out), "audit": audit,
+            "verified": "output == input + s_setprio insertions + add3 splits (isa_prio_pass.verify)"}
     with open(os.path.splitext(target)[0] + ".isa.json", "w") as f:
         json.dump(info, f, indent=1)
     return target
@@ -151,6 +174,12 @@ def build_experiments(force=False):
     """Tools build (-DVKMR_EXPERIMENTS): the A/B knobs VKMR_MAP_VARIANT/_FIT/_TILE/_DYNLDS and the non-shipped
     map_kernel instantiations (csrc/map_experiments.hpp).  Lands under build/ab/, not in the package."""
     return _build_hip_variant(EXP_LIB, ["-DVKMR_EXPERIMENTS"], force)
+
+
+def build_experiments_stamps(force=False):
+    """The experiments build with the in-kernel stamps as well (tools/kernel_clock.py --lib build/ab/libexp_stamps.so with
+    VKMR_MAP_VARIANT set): clock and phase shares of a variant that is not the shipped one."""
+    return _build_hip_variant(os.path.join(ROOT, "build", "ab", "libexp_stamps.so"), ["-DVKMR_EXPERIMENTS", "-DVKMR_STAMPS"], force)
 
 
 def build_host(force=False):

@@ -195,8 +195,14 @@ uint32_t HipSha256D::Instance::ChooseSliceLog2(const char* first_span, size_t le
     uint32_t fits = 40;   // no memory figure from any device: nothing to clamp against (an allocation that fails is still reported)
     if (free_min != ~(size_t)0) {
         const double room = 0.85 * (double)free_min - landing;
+        // slices resident at once for a candidate size: the configured budget, or -- everything staged before the first map
+        // (StagePacked) -- every slice the expected leaves fill, plus the one being filled
+        auto resident = [&](uint32_t log2) -> double {
+            if (m_cfg.expected_leaves == 0) return (double)budget;
+            return (double)((m_cfg.expected_leaves + (((uint64_t)1 << log2) - 1)) >> log2) + 1.0;
+        };
         fits = 1;
-        while (fits < 40 && (double)((size_t)1 << (fits + 1)) * (32.0 * (double)budget + 12.0) <= room) ++fits;
+        while (fits < 40 && (double)((size_t)1 << (fits + 1)) * (32.0 * resident(fits + 1) + 12.0) <= room) ++fits;
     }
     uint32_t wanted = 23;
     *why = "the reference's 256 MiB slice (src/vkmr/SHA-256vk.cpp:23)";
@@ -237,6 +243,10 @@ bool HipSha256D::Instance::EnsureGeometry(const char* first_span, size_t len)
     m_cfg.slice_log2 = ChooseSliceLog2(first_span, len, &why);
     if (m_cfg.verbose) std::cout << "Slices of 2^" << m_cfg.slice_log2 << " digests (" << why << ")." << std::endl;
     const size_t capacity = (size_t)1 << m_cfg.slice_log2;
+    if (m_cfg.expected_leaves) {   // the budget follows the size actually chosen, not the one the caller guessed
+        const size_t need = (size_t)((m_cfg.expected_leaves + capacity - 1) >> m_cfg.slice_log2) + 1;
+        if (need > m_cfg.slice_budget) m_cfg.slice_budget = need;
+    }
     m_slices = Slices(m_device_ids, capacity, m_cfg.slice_budget ? m_cfg.slice_budget : m_cfg.max_inflight + 1);
     m_reductions = Reductions::New(m_device_ids, capacity, m_cfg.verbose);
     if (!m_reductions->Ok()) m_ok = false;   // reported by Reductions::New
@@ -261,7 +271,10 @@ void HipSha256D::Instance::StartPrefetch()
 
 HipSha256D::Instance::~Instance()
 {
-    // ops first (they hold batches and slices), then the pools and streams
+    // staged batches and their slice views first: each holds a raw pointer to its pool (Batch::Release -> Batches::Recycle),
+    // and the pools go below (a failed StagePacked / RootOfStaged leaves them here)
+    m_staged.clear();
+    // ops next (they hold batches and slices), then the pools and streams
     m_pool.reset();
     m_mappings.reset();
     m_reductions.reset();
@@ -590,13 +603,15 @@ bool HipSha256D::Instance::StagePacked(const uint32_t* data, const vkmr_metadata
         st.batch = std::move(m_batch);
         m_staged.push_back(std::move(st));
     };
+    // a failure gives up what was staged: the batches go back to their pools while the pools are alive
+    auto give_up = [&] { m_staged.clear(); return false; };
     size_t pos = 0;
     while (pos < count) {
         if (!m_slices.Current()) {
-            if (!StartSliceAndBatch()) return false;
+            if (!StartSliceAndBatch()) return give_up();
         } else if (m_slices.Current().Available() == 0) {
             stage_current();
-            if (!StartSliceAndBatch()) return false;
+            if (!StartSliceAndBatch()) return give_up();
         }
         Slice& slice = m_slices.Current();
         const size_t took = m_batch.PushPacked(data, meta + pos, count - pos, slice.Available());
@@ -608,10 +623,10 @@ bool HipSha256D::Instance::StagePacked(const uint32_t* data, const vkmr_metadata
             const int dev = slice.Device();
             if (m_batch.Empty()) {
                 std::cerr << "A packed string does not fit an empty batch." << std::endl;
-                return false;
+                return give_up();
             }
             stage_current();
-            if (!NewBatch(dev)) return (m_ok = false);
+            if (!NewBatch(dev)) { m_ok = false; return give_up(); }
         }
     }
     return true;
@@ -635,7 +650,10 @@ ISha256D::out_type HipSha256D::Instance::RootOfStaged()
         if (m_mappings->InFlight()) Account(m_mappings->Update());
         if (m_mappings->InFlight() >= m_cfg.max_inflight) Account(m_mappings->WaitUntilAtMost(m_cfg.max_inflight - 1));
         PerDevice& pd = Dev(st.dev);
-        if (!m_ok || m_mappings->Map(std::move(st.batch), std::move(st.sub), pd.map_stream, pd.copy_stream) != VKMR_OK) return "";
+        if (!m_ok || m_mappings->Map(std::move(st.batch), std::move(st.sub), pd.map_stream, pd.copy_stream) != VKMR_OK) {
+            m_staged.clear();   // nothing staged outlives the failure (the pools it points into go with the instance)
+            return "";
+        }
     }
     m_staged.clear();
     return Root();

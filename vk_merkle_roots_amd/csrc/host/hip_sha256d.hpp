@@ -26,6 +26,7 @@ struct HipConfig {
                                      // sets it; a value that does not fit is clamped with a message
     bool slice_log2_given = false;   // slice_log2 came from the caller (VKMR_SLICE_LOG2), not from the default
     uint64_t expected_input_bytes = 0;  // bytes stdin will deliver when that is known (a regular file), else 0
+    uint64_t expected_leaves = 0;       // strings the caller will stage before anything is mapped (StagePacked): every slice of them is resident at once
     size_t batch_bytes = 40u << 20;  // data bytes per batch.  The reference prefers 256 MiB (MegaX, SHA-256vk.cpp:23,
                                      // :247-248).  Here a batch holds one 32 MiB span of stdin (vkmr_main) with room for
                                      // the padding of short lines; pinning it (50 MiB with its metadata) is 8 ms, and

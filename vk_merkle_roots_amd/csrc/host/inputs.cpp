@@ -10,6 +10,7 @@
 #include <thread>
 
 #include <fcntl.h>
+#include <poll.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -27,9 +28,13 @@ struct Input::Reader {
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false;
+    int error = 0;              // errno of the read that failed, if one did (read under mu)
 
+    // fd: this thread's OWN descriptor (a dup of the stream's): the Input may close its FILE while the thread sits in read(2),
+    // and a number that is closed can be handed to the next open() of the process.  Closed here, when the thread ends.
     static void Run(std::shared_ptr<Reader> self, int fd, std::vector<char> tail)
     {
+        struct Closer { int fd; ~Closer() { if (fd >= 0) close(fd); } } closer{fd};
         static const size_t kBlock = (size_t)16 << 20, kEnough = (size_t)8 << 20;
         for (;;) {
             Block* b = nullptr;
@@ -51,7 +56,18 @@ struct Input::Reader {
                 if (end == b->data.size()) b->data.resize(b->data.size() * 2);   // a line longer than the block
                 const ssize_t got = read(fd, b->data.data() + end, b->data.size() - end);
                 if (got < 0 && errno == EINTR) continue;
+                if (got < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {   // a non-blocking stdin: wait for it, this is not the end
+                    struct pollfd pfd = {fd, POLLIN, 0};
+                    (void)poll(&pfd, 1, 1000);
+                    std::lock_guard<std::mutex> lock(self->mu);
+                    if (self->stop) return;
+                    continue;
+                }
                 if (got <= 0) {
+                    if (got < 0) {   // EIO, EBADF ...: the stream ends here, and the caller is told why
+                        std::lock_guard<std::mutex> lock(self->mu);
+                        self->error = errno ? errno : EIO;
+                    }
                     eof = true;
                     break;
                 }
@@ -133,8 +149,25 @@ size_t Input::ReadSome(char* dst, size_t n)
     for (;;) {   // read(2), not fread: what a pipe holds now is worth having now
         const ssize_t got = read(fileno(m_fp), dst, n);
         if (got >= 0) return (size_t)got;
-        if (errno != EINTR) return 0;
+        if (errno == EINTR) continue;
+        if (errno == EAGAIN || errno == EWOULDBLOCK) {
+            struct pollfd pfd = {fileno(m_fp), POLLIN, 0};
+            (void)poll(&pfd, 1, 1000);
+            continue;
+        }
+        m_error = errno ? errno : EIO;
+        return 0;
     }
+}
+
+int Input::Error() const
+{
+    if (m_error) return m_error;
+    if (m_reader) {
+        std::lock_guard<std::mutex> lock(m_reader->mu);
+        return m_reader->error;
+    }
+    return 0;
 }
 
 bool Input::Fill()
@@ -214,7 +247,9 @@ bool Input::GetBlock(const char** p, size_t* n, bool* final)
         for (auto& blk : m_reader->blocks) m_reader->free.push_back(&blk);
         std::vector<char> tail(m_buf.begin() + (long)m_pos, m_buf.begin() + (long)m_end);
         m_pos = m_end = 0;
-        std::thread(Reader::Run, m_reader, m_fp ? fileno(m_fp) : -1, std::move(tail)).detach();
+        const int own = m_fp ? dup(fileno(m_fp)) : -1;
+        if (m_fp && own < 0) m_error = errno ? errno : EMFILE;   // the thread then reads nothing: the stream ends at once, with this error
+        std::thread(Reader::Run, m_reader, own, std::move(tail)).detach();
     }
     Reader& r = *m_reader;
     std::unique_lock<std::mutex> lock(r.mu);

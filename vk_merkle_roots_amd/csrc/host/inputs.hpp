@@ -37,6 +37,11 @@ public:
     // '\n').  After the final span Has() is false.  Lines longer than the buffer grow it.
     bool GetBlock(const char** p, size_t* n, bool* final);
 
+    // errno of a read that FAILED (not one that reached the end of the stream), else 0.  A stream cut short by an error still
+    // ends -- Has() turns false -- and the caller decides: vkmr prints the error and no root (a root over a truncated input
+    // would look like an answer).
+    int Error() const;
+
     size_type Size() const { return m_size; }
     size_type Count() const { return m_count; }
 
@@ -47,6 +52,7 @@ private:
     std::shared_ptr<Reader> m_reader;
 
     FILE* m_fp;
+    int m_error = 0;
     bool m_owner, m_eof;
     size_type m_size, m_count;
     std::vector<char> m_buf;

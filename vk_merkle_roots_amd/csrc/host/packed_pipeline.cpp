@@ -37,9 +37,12 @@ __attribute__((visibility("default"))) int vkmr_host_pipeline_packed(int device,
     cfg.batch_bytes_max = cfg.batch_bytes;
     cfg.max_inflight = (size_t)nbatches + 1;
     if (slice_log2) { cfg.slice_log2 = slice_log2; cfg.slice_log2_given = true; }
+    // every slice is staged before the first is reduced: the budget is what `count` strings fill at the slice size in use --
+    // the given one, or whatever the instance chooses from the device's memory (it raises the budget itself then)
     uint32_t sl = slice_log2 ? slice_log2 : 23;
     const uint64_t nslices = (count + ((uint64_t)1 << sl) - 1) >> sl;
     cfg.slice_budget = (size_t)nslices + 1;
+    cfg.expected_leaves = count;
     auto inst = gpus.Get(name, cfg);
     if (!inst || !inst->Ok()) return -1;
     // stage, batch by batch (strings_per_batch strings each: the launch shape asked for)

@@ -108,6 +108,7 @@ LineCount totals_of(const LineIndex& ix)
 LineCount IndexLinesPortable(const uint8_t* buf, size_t len, LineIndex* ix)
 {
     ix->Reserve(len + 1);
+    if (!ix->ends) { ix->count = 0; return LineCount(); }   // no memory for the index: the callers test `ends` and take the serial form
     uint32_t* o = ix->ends;
     size_t pos = 0;
     while (pos < len) {
@@ -254,6 +255,7 @@ __attribute__((target("avx2"))) PackResult PackLinesAvx2(const uint8_t* buf, siz
 __attribute__((target("avx2,bmi,popcnt"))) LineCount IndexLinesAvx2(const uint8_t* buf, size_t len, LineIndex* ix)
 {
     ix->Reserve(len + 1);
+    if (!ix->ends) { ix->count = 0; return LineCount(); }   // no memory for the index: the callers test `ends` and take the serial form
     uint32_t* o = ix->ends;
     size_t blk = 0;
     for (; blk + 64 <= len; blk += 64) {

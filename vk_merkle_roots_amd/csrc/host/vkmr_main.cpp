@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -43,6 +44,11 @@ static int run(vkmr::ISha256D& backend)
         for (size_t i = 0; i < tally.empties; ++i) std::cerr << "Read an empty string?" << std::endl;
         size += tally.bytes;
         count += tally.items;
+    }
+    if (const int err = input.Error()) {
+        // the stream did not end, it broke (EIO, a descriptor gone bad): a root over what arrived would look like an answer
+        std::cerr << "Reading the input failed after " << count << " item(s): " << strerror(err) << "; no root." << std::endl;
+        return 2;
     }
     if (count > 0) {
         const std::string root = backend.Root();

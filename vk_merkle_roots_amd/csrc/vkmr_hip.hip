@@ -71,10 +71,15 @@ const char* vkmr_hip_last_error(void) { return g_err; }
 // diagnostic build only: copies the stamp buffer out and clears it for the next launch
 __attribute__((visibility("default"))) int vkmr_hip_debug_stamps(unsigned long long* out, int words)
 {
+    // The callers' streams are non-blocking ones: nothing orders them against the copy and the memset below (both on the
+    // null stream) but these two device-wide waits.
+    if (words < 0 || words > VKMR_STAMP_SLOTS * 8) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * words) != hipSuccess) return -1;
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return -1;
-    return hipMemset(p, 0, sizeof(unsigned long long) * VKMR_STAMP_SLOTS * 8) == hipSuccess ? 0 : -1;
+    if (hipMemset(p, 0, sizeof(unsigned long long) * VKMR_STAMP_SLOTS * 8) != hipSuccess) return -1;
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -28,6 +28,23 @@ SIMPLE = {
     "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32",
     "v_mov_b32", "v_bitop3_b32", "v_cndmask_b32", "v_accvgpr_write_b32", "v_accvgpr_read_b32", "v_nop",
 }
+# Complex VALU opcodes whose one-per-turn issue was MEASURED (profiles/r03_issue_patterns_set1-5.txt, r01_valu_issue_rates.txt):
+# exact names, and prefixes ending in "*".  classify() treats every opcode outside SIMPLE as complex -- the safe price -- but a
+# toolchain that starts to emit an opcode nobody measured must not move bench.py's floor silently: audit() below lists those.
+COMPLEX_MEASURED = {
+    "v_alignbit_b32", "v_add3_u32", "v_perm_b32", "v_lshlrev_b32", "v_cndmask_b32", "v_bitop3_b32", "v_cmp_*", "v_cmpx_*",
+    "v_lshlrev_b64", "v_lshrrev_b64", "v_lshl_add_u64", "v_mov_b64", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32",
+}
+# Complex by assumption (address arithmetic and lane traffic at the edges of a hash block; never in the round function): priced
+# as complex, tolerated up to this many PER HASH BLOCK -- more means the compiler has begun to use one inside the rounds.
+COMPLEX_ASSUMED = {"v_add_lshl_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_sub_co_u32", "v_subrev_co_u32", "v_subb_co_u32", "v_subbrev_co_u32", "v_add_co_u32",
+                   "v_addc_co_u32", "v_writelane_b32", "v_readlane_b32", "v_readfirstlane_b32", "v_min_u32", "v_max_u32", "v_and_or_b32", "v_or3_b32"}
+ASSUMED_PER_BLOCK = 16
+# Hash blocks every kernel must show (hash_blocks()): the node hash once per code path that hashes pairs, a 64-byte block and
+# the digest hash per map_kernel instantiation.  A listing with other counts is not the code the static counts were taken from.
+EXPECTED_HASH_BLOCKS = {"reduce_pass_kernel": 1, "reduce_level_kernel": 1, "reduce_collapse_kernel": 2, "reduce_tail_kernel": 2, "map_kernel": 2,
+                        "map_persist_kernel": 4, "map_hash_sorted_kernel": 2}   # the last two: experiments build (staged + per-lane loop; block + digest)
+
 _INSTR = re.compile(r"^\s+([a-z_0-9]+)\s*(.*)$")
 _LABEL = re.compile(r"^[.\w$]+:")
 
@@ -228,6 +245,107 @@ def hash_blocks(lines):
             close()
             cur, bb = None, None
     return {k: v for k, v in out.items() if v}
+
+
+def _base(op):
+    return re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+
+
+def _known(base):
+    if base in SIMPLE or base in COMPLEX_MEASURED:
+        return "measured"
+    if any(p.endswith("*") and base.startswith(p[:-1]) for p in COMPLEX_MEASURED):
+        return "measured"
+    if base in COMPLEX_ASSUMED:
+        return "assumed"
+    return None
+
+
+def audit(lines):
+    """The guard between the issue model and the compiler.  Over the SHA-256 basic blocks of a (transformed)
+    listing -- the blocks bench.py's floor is computed from -- returns
+        {"hash_valu": {mnemonic: count}, "unclassified": [...], "blocks": {kernel: n}, "block_count_errors": [...]}
+    `unclassified` names every VALU mnemonic in a hash block that is neither in SIMPLE nor in COMPLEX_MEASURED, and every
+    COMPLEX_ASSUMED one used more than ASSUMED_PER_BLOCK times in one block; `block_count_errors` every kernel whose number of
+    hash blocks is not EXPECTED_HASH_BLOCKS'.  Both must be empty for the static counts to mean what DESIGN.md 3.1 says."""
+    hist, unclassified, blocks = {}, [], {}
+    cur, ops, rot = None, {}, 0
+
+    def close():
+        nonlocal ops, rot
+        if cur is not None and rot > 100:
+            blocks[cur] = blocks.get(cur, 0) + 1
+            for b, n in ops.items():
+                hist[b] = hist.get(b, 0) + n
+                k = _known(b)
+                if k is None:
+                    unclassified.append(f"{cur}: {b} x{n} (not measured)")
+                elif k == "assumed" and n > ASSUMED_PER_BLOCK:
+                    unclassified.append(f"{cur}: {b} x{n} in one hash block (assumed complex, tolerated up to {ASSUMED_PER_BLOCK})")
+        ops, rot = {}, 0
+    for ln in lines:
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            close()
+            cur = m.group(1)
+            continue
+        if cur is None:
+            continue
+        if re.match(r"^\.LBB\w+:", ln):
+            close()
+            continue
+        if classify(ln) in ("C", "S"):
+            b = _base(_INSTR.match(ln).group(1))
+            ops[b] = ops.get(b, 0) + 1
+            if b == "v_alignbit_b32":
+                rot += 1
+        if ln.strip().startswith("s_endpgm"):
+            close()
+            cur = None
+    errors = []
+    for kernel, n in sorted(blocks.items()):
+        want = next((v for k, v in EXPECTED_HASH_BLOCKS.items() if k in kernel), None)
+        if want is None:
+            errors.append(f"{kernel}: {n} hash block(s) in a kernel nobody listed in EXPECTED_HASH_BLOCKS")
+        elif n != want:
+            errors.append(f"{kernel}: {n} hash block(s), expected {want}")
+    return {"hash_valu": dict(sorted(hist.items())), "unclassified": sorted(set(unclassified)), "blocks": blocks, "block_count_errors": errors}
+
+
+def verify(original, transformed):
+    """Build-time self-check: the transformed listing is the original plus inserted `s_setprio` lines, with some
+    `v_add3_u32 d, a, b, c` replaced by two `v_add_u32` that add the same three operands into d -- and nothing else.
+    Returns a list of differences (empty = verified)."""
+    diffs = []
+    i = j = 0
+    n, m = len(original), len(transformed)
+    prio = re.compile(r"^\ts_setprio \d+\n?$")
+    add = re.compile(r"^\s+v_add_u32_e32\s+(v\d+),\s*([^,]+),\s*([^,\s]+)\s*$")
+    while i < n or j < m:
+        if i < n and j < m and original[i] == transformed[j]:
+            i += 1; j += 1
+            continue
+        if j < m and prio.match(transformed[j]):
+            j += 1
+            continue
+        a3 = _ADD3.match((original[i].split(";")[0].rstrip() if ";" in original[i] else original[i].rstrip("\n"))) if i < n else None
+        if a3 and j + 1 < m:
+            x, y = add.match(transformed[j].rstrip("\n")), add.match(transformed[j + 1].rstrip("\n"))
+            if x and y:
+                d = a3.group(2)
+                srcs = sorted(t.strip() for t in (a3.group(3), a3.group(4), a3.group(5)))
+                first = [x.group(2).strip(), x.group(3).strip()]
+                second = [y.group(2).strip(), y.group(3).strip()]
+                if x.group(1) == d and y.group(1) == d and d in second:
+                    second.remove(d)
+                    if sorted(first + second) == srcs and second[0] != d:
+                        i += 1; j += 2
+                        continue
+        diffs.append(f"line {i + 1} of the input / {j + 1} of the output: {(original[i] if i < n else '<end>').strip()!r} vs {(transformed[j] if j < m else '<end>').strip()!r}")
+        if len(diffs) >= 8:
+            break
+        i += 1; j += 1
+    return diffs
 
 
 def main(argv):
