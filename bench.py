@@ -71,6 +71,7 @@ def parse():
     p.add_argument("--force-dist", action="store_true", help="form the process group and the RCCL communicator even with one rank")
     p.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive (pinned host -> root) measurement")
     p.add_argument("--no-long-strings", action="store_true", help="skip the secondary long-string map measurement")
+    p.add_argument("--no-config5", action="store_true", help="skip the configs[4] full-size leg (rndm 42 2^24 4096 through map + reduce: about a minute of host-side generation)")
     return p.parse_args()
 
 
@@ -305,6 +306,89 @@ def long_strings_rate(dev, vk, seed, count_log2=21, maxlen=4096, launches=10):
             "blocks": blocks, "compressions_per_string": blocks / n + 1}
 
 
+def config5_full(dev, vk, seed, count_log2=24, maxlen=4096, batch_log2=20, slice_log2=23):
+    """BASELINE configs[4] at full size through the whole path: `rndm <seed> 2^24 4096` (34 GB of text, 1..65 blocks per string)
+    streamed as 16 packed batches of 2^20 strings (a packed batch addresses at most 2^32 words) -- each generated on the host,
+    uploaded, then mapped with the input RESIDENT in HBM (the timed part: HIP events around every map launch) -- into 2
+    slices of 2^23 digests (the reference's slice), one batched reduction of the slices, the combine of the two roots.
+    `value` stays configs[2]'s figure; this block is the measured record of configs[4] (VERDICT r3 #2 / Missing #3)."""
+    from vk_merkle_roots_amd.engine import digest_hex, tree_height
+    from vk_merkle_roots_amd import provenance
+    n, per, cap = 1 << count_log2, 1 << batch_log2, 1 << slice_log2
+    nslices = n // cap
+    stream = vk.RndmStream(seed, maxlen)
+    d_digests = dev.alloc(32 * n)
+    d_scratch = dev.alloc(dev.lib.vkmr_hip_reduce_slices_scratch_bytes(cap, nslices))
+    d_roots, d_top, d_final = dev.alloc(32 * nslices), dev.reduce_scratch(max(nslices, 2)), dev.alloc(32)
+    e0, e1 = dev.new_event(), dev.new_event()
+    map_ms, words_total, blocks, payload = [], 0, 0, 0
+    t_host = time.perf_counter()
+    info = None
+    for b0 in range(0, n, per):
+        batch = stream.next(per)
+        d_data, d_meta = dev.upload(batch.data), dev.upload(batch.meta)
+        dev.map_async(d_data, batch.words, d_meta, per, d_digests, out_offset_digests=b0)   # first touch of this batch's buffers: untimed
+        dev.sync()
+        dev.record(e0)
+        dev.map_async(d_data, batch.words, d_meta, per, d_digests, out_offset_digests=b0)
+        dev.record(e1)
+        dev.sync()
+        map_ms.append(dev.elapsed_ms(e0, e1))
+        info = info or dev.lib.vkmr_hip_kernel_info().decode()
+        words_total += batch.words
+        sizes = batch.meta[:, 1].astype(np.int64)
+        blocks += int(((sizes + 8) // 64 + 1).sum())
+        payload += int(sizes.sum())
+        d_data.free()
+        d_meta.free()
+    stream.close()
+    host_s = time.perf_counter() - t_host
+
+    def reduce_all():
+        dev.reduce_slices_async(d_digests, nslices, cap, cap, slice_log2, d_scratch, d_roots)
+        dev.reduce_async(d_roots, nslices, tree_height(nslices), d_top, d_final)
+    reduce_all()
+    dev.sync()
+    red_ms = []
+    for _ in range(5):
+        dev.record(e0)
+        reduce_all()
+        dev.record(e1)
+        dev.sync()
+        red_ms.append(dev.elapsed_ms(e0, e1))
+    root = digest_hex(dev.download(d_final, 32))
+    for b in (d_digests, d_scratch, d_roots, d_top, d_final):
+        b.free()
+    total_map, red = float(np.sum(map_ms)), float(np.median(red_ms))
+    golden = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "tests", "golden", "big_roots.json"))).get("config5")
+        if rec and rec.get("generator") == f"rndm {seed} {n} {maxlen}":
+            golden = rec
+    except (OSError, ValueError):
+        pass
+    nbytes = words_total * 4 + 40 * n      # packed words + 8 B entry read, 32 B digest written, per string
+    pmc = provenance.load_pmc()
+    traffic, tsrc = provenance.traffic_from_pmc(dict(pmc or {}, map_kernel_symbol=(pmc or {}).get("long_strings_map_kernel_symbol")), info,
+                                                "long_strings_map_hbm_bytes_per_launch", long_strings_workload=f"rndm {seed} 2^21 {maxlen}, one batch")
+    # the counter record is of ONE batch of 2^21 strings of the same distribution and the same kernel: scaled by the strings here
+    if traffic is not None:
+        traffic = traffic * n / float(1 << 21)
+        tsrc = dict(tsrc or {}, scaled="per-launch record of 2^21 strings of the same distribution x 8 (2^24 strings)")
+    return {"workload": f"rndm {seed} 2^{count_log2} {maxlen} (BASELINE configs[4]), {n // per} packed batches of 2^{batch_log2} strings, {nslices} slices of 2^{slice_log2}",
+            "strings": n, "payload_bytes": payload, "packed_bytes": int(words_total * 4), "blocks": blocks, "compressions_per_string": blocks / n + 1,
+            "map_ms_total": total_map, "map_ms_per_batch": [round(x, 4) for x in map_ms], "reduce_and_combine_ms": red,
+            "ms_total": total_map + red, "leaf_hashes_per_s": n / ((total_map + red) * 1e-3), "input_GBps": words_total * 4 / (total_map * 1e-3) / 1e9,
+            "map_mode": (info or "").split(" reduce=")[0], "root": root,
+            "root_matches": (root == golden["root"]) if golden else None,
+            "golden": "tests/golden/big_roots.json config5 (the reference's CPU path on the same stream)" if golden else None,
+            "roofline": {"bound": "hbm", "kernel": "map_kernel (" + (provenance.map_symbol_of(info or "") or "?") + ")", "achieved": nbytes / (total_map * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (total_map * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": tsrc, "algorithmic_bytes": int(nbytes)},
+            "host_seconds_generating_and_uploading": host_s,
+            "what": "resident-input kernel time of all 16 map launches + one batched reduction of 2 slices + combine; generation and upload of each batch are outside the timed region"}
+
+
 def hip_all_check(timeout_s=120):
     """On a multi-GPU node: the C++ front end's one-process path, `rndm 42 2^20 127 | vkmr hip:all` with slices of
     2^17 -- eight slices dealt over the node's GPUs, ONE RCCL all-gather of their roots inside that process
@@ -364,14 +448,15 @@ def static_counts():
     return out
 
 
-def clock_leg(seed, maxlen, leaves_log2=24):
+def clock_leg(seed, maxlen, leaves_log2):
     """The shader clock map_kernel and reduce_pass_kernel HOLD, measured in-kernel (s_memtime against the constant-rate
     s_memrealtime, per workgroup, after 2 s of back-to-back launches) by tools/kernel_clock.py in a child process on
-    the stamped twin of the library (same source, -DVKMR_STAMPS; in the product no stamp executes)."""
+    the stamped twin of the library (same source, -DVKMR_STAMPS; in the product no stamp executes).  Same workload SIZE as the
+    timed steps: the clock a 5 ms launch holds is not the one a 1.3 ms launch holds (profiles/r04_kernel_clock_fault.txt)."""
     tool = os.path.join(ROOT, "tools", "kernel_clock.py")
     try:
         r = subprocess.run([sys.executable, tool, "--leaves-log2", str(leaves_log2), "--maxlen", str(maxlen), "--seed", str(seed)],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, env={k: v for k, v in os.environ.items() if k != "VKMR_HIP_LIB"})
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400, env={k: v for k, v in os.environ.items() if k != "VKMR_HIP_LIB"})
         rec = json.loads(r.stdout.decode().strip().splitlines()[-1])
     except Exception as e:   # the leg must not take the bench line down with it
         return {"error": repr(e)[:200]}
@@ -394,6 +479,32 @@ def issue_block(units, valu_per_unit, turns_per_unit, ms, clock_ghz):
                    floor_ms_at_measured_clock=per_simd * turns_per_unit * 4 / (clock_ghz * 1e6),
                    frac_of_floor=per_simd * turns_per_unit * 4 / cycles)
     return out
+
+
+def gather_label(distributed, through_abi):
+    """What carries the sub-tree roots between ranks, as the JSON line names it."""
+    if not distributed:
+        return None
+    return ("vkmr_hip_gather_roots_async: 1 ncclAllGather of 32 B per rank (C ABI, librccl)" if through_abi
+            else "torch.distributed gather over gloo (rehearsal)")
+
+
+def workload_label(seed, leaves_log2, maxlen, world):
+    return (f"rndm {seed}+rank 2^{leaves_log2} {maxlen} per GPU (BASELINE configs[{2 if world == 1 else 3}]"
+            f"{'' if world in (1, 8) else ' shape at ' + str(world) + ' GPUs'})")
+
+
+def check_against_golden(golden, seed, world, root_hex, sub_roots):
+    """(root_matches_golden, sub_roots_match_golden): the timed path's root and every rank's sub-tree root against what the
+    reference's CPU path printed for these streams (tests/golden/big_roots.json: sub-roots of seeds 42..49, and their
+    combination in rank order for 1..8 ranks); None where the file has no entry."""
+    if not golden:
+        return None, None
+    want = golden.get("combined", {}).get(str(world))
+    root_ok = (root_hex == want) if want else None
+    have = [golden["sub_roots"].get(str(seed + r), {}).get("root") for r in range(world)]
+    subs_ok = (sub_roots == have) if all(have) else None
+    return root_ok, subs_ok
 
 
 def golden_big_roots(leaves_log2, maxlen):
@@ -626,12 +737,7 @@ def main():
                      else [digest_hex(dev.download(d_sub, 32))])
         # the timed path's own result against what the reference CPU path printed for these streams
         golden = golden_big_roots(a.leaves_log2, a.maxlen) if a.seed == 42 else None
-        root_ok = subs_ok = None
-        if golden:
-            want = golden.get("combined", {}).get(str(world))
-            root_ok = (root_hex == want) if want else None
-            have = [golden["sub_roots"].get(str(a.seed + r), {}).get("root") for r in range(world)]
-            subs_ok = (sub_roots == have) if all(have) else None
+        root_ok, subs_ok = check_against_golden(golden, a.seed, world, root_hex, sub_roots)
         # algorithmic bytes of one map launch: packed words + 8 B metadata read, 32 B digest written
         map_bytes = (batch.words * 4 + 8 * n + 32 * n) / nbatches
         achieved = map_bytes / (map_launch_ms * 1e-3) / 1e9
@@ -655,14 +761,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"rndm {a.seed}+rank 2^{a.leaves_log2} {a.maxlen} per GPU (BASELINE configs[{2 if world == 1 else 3}]"
-                                   f"{'' if world in (1, 8) else ' shape at ' + str(world) + ' GPUs'})",
+            "config": {"workload": workload_label(a.seed, a.leaves_log2, a.maxlen, world),
                        "leaves_per_gpu": n, "leaves_total": total_leaves, "slices_per_gpu": nslices, "slice_capacity": cap,
                        "map_launches_per_step": nbatches, "input_bytes_per_gpu": int(input_bytes),
                        "parallelism": f"one process per GPU, slices sharded over {world} GPU(s), no data-path collective but the root gather",
                        "collective": collective, "ranks": world,
-                       "gather": (None if dist is None else ("vkmr_hip_gather_roots_async: 1 ncclAllGather of 32 B per rank (C ABI, librccl)" if comm is not None
-                                                             else "torch.distributed gather over gloo (rehearsal)")),
+                       "gather": gather_label(dist is not None, comm is not None),
                        "bytes_gathered_per_step": (32 * world if dist is not None else 0),
                        "kernels": kernel_info, "reduce_variant": "levels" if a.levels_variant else "wave",
                        "rccl": dev.lib.vkmr_hip_comm_info().decode()},
@@ -745,32 +849,46 @@ def main():
             out["from_file_on_stdin"] = ff
         if world == 1 and not a.no_long_strings:
             out["long_strings"] = long_strings_rate(dev, vk, a.seed)
+        if world == 1 and not a.no_config5 and not a.no_long_strings and a.leaves_log2 >= 24:
+            try:
+                out["config5_full"] = config5_full(dev, vk, a.seed)
+            except Exception as e:   # out of host or device memory on an unusual box: the leg is reported as failed, the line is still printed
+                out["config5_full"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # ---- the bound the path sits under: VALU issue at the clock each kernel holds -------------------------------
-        counts = static_counts()
-        clk = None if (a.no_clock_leg or world > 1) else clock_leg(a.seed, a.maxlen)
-        vr = {"bound": "VALU issue: a gfx950 SIMD issues at most two VALU instructions per 4-cycle turn -- one of any kind plus one simple one "
-                       "(add/sub, and/or/xor, shift right, v_bitop3 on VGPRs); floor = max(N / 2, N_complex) turns per hash (DESIGN.md 3)",
-              "static_counts": counts, "clock": clk,
-              "map_ms_per_step": map_launch_ms * nbatches, "reduce_ms_per_step": red_step_ms}
-        if counts and counts.get("node"):
-            mode = provenance.map_symbol_of(kernel_info)
-            key = mode[len("map_kernel<"):-1].replace("false", "0").replace("true", "1") if mode else None   # as the mangled names spell it
-            mc = counts["map"].get(key) if key else None
-            ghz = lambda k: (clk or {}).get(k, {}).get("GHz_median") if clk and "error" not in clk else None   # noqa: E731
-            node = counts["node"]
-            vr["reduce"] = issue_block(n - 1, node["valu"], max(node["valu"] / 2.0, node["complex"]), red_step_ms, ghz("reduce_pass_kernel"))
-            if mc:
-                bpl = blocks / n
-                valu = bpl * mc["block"]["valu"] + mc["digest"]["valu"]
-                cplx = bpl * mc["block"]["complex"] + mc["digest"]["complex"]
-                vr["map"] = issue_block(n, valu, max(valu / 2.0, cplx), map_launch_ms * nbatches, ghz("map_kernel"))
-                vr["map"]["blocks_per_leaf"] = bpl
-        out["valu_roofline"] = vr
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.seed, a.maxlen, a.leaves_log2 if a.cpu_sample_log2 is None else min(a.cpu_sample_log2, a.leaves_log2),
-                                               a.leaves_log2)
-            if out["cpu_baseline"].get("root") and out["cpu_baseline"]["leaves"] == n:
-                out["cpu_baseline"]["root_matches_gpu"] = out["cpu_baseline"]["root"] == root_hex
+        def valu_roofline_block(clk):
+            counts = static_counts()
+            vr = {"bound": "VALU issue: a gfx950 SIMD issues at most two VALU instructions per 4-cycle turn -- one of any kind plus one simple one "
+                           "(add/sub, and/or/xor, shift right, v_bitop3 on VGPRs); floor = max(N / 2, N_complex) turns per hash (DESIGN.md 3)",
+                  "static_counts": counts, "clock": clk,
+                  "map_ms_per_step": map_launch_ms * nbatches, "reduce_ms_per_step": red_step_ms}
+            if counts and counts.get("node"):
+                mode = provenance.map_symbol_of(kernel_info)
+                key = mode[len("map_kernel<"):-1].replace("false", "0").replace("true", "1") if mode else None   # as the mangled names spell it
+                mc = counts["map"].get(key) if key else None
+                ghz = lambda k: (clk or {}).get(k, {}).get("GHz_median") if clk and "error" not in clk else None   # noqa: E731
+                node = counts["node"]
+                vr["reduce"] = issue_block(n - 1, node["valu"], max(node["valu"] / 2.0, node["complex"]), red_step_ms, ghz("reduce_pass_kernel"))
+                if mc:
+                    bpl = blocks / n
+                    valu = bpl * mc["block"]["valu"] + mc["digest"]["valu"]
+                    cplx = bpl * mc["block"]["complex"] + mc["digest"]["complex"]
+                    vr["map"] = issue_block(n, valu, max(valu / 2.0, cplx), map_launch_ms * nbatches, ghz("map_kernel"))
+                    vr["map"]["blocks_per_leaf"] = bpl
+            return vr
+
+        def cpu_baseline_block():
+            cb = cpu_baseline(a.seed, a.maxlen, a.leaves_log2 if a.cpu_sample_log2 is None else min(a.cpu_sample_log2, a.leaves_log2), a.leaves_log2)
+            if world > 1:
+                cb["sample"] = f"rank 0's stream only -- 1/{world} of the workload: " + cb["sample"]
+            want = sub_roots[0] if world > 1 else root_hex      # rank 0's sub-tree root is the root of exactly this stream
+            if cb.get("root") and cb["leaves"] == n:
+                cb["root_matches_gpu"] = cb["root"] == want
+            return cb
+
+        if world == 1:
+            out["valu_roofline"] = valu_roofline_block(None if a.no_clock_leg else clock_leg(a.seed, a.maxlen, a.leaves_log2))
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_block()
     # Every rank leaves the data path together BEFORE rank 0 runs its one-process probe: the other ranks must not sit in
     # a barrier under the watchdog while rank 0 spends up to two minutes in child processes, and must not tear their
     # communicators down while it still uses the GPUs.
@@ -781,6 +899,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if world > 1:
+            # An N > 1 line carries what the N = 1 line carries: the in-kernel clock (rank 0's GPU, the same
+            # per-GPU workload) and the reference's CPU path timed on rank 0's stream -- after every rank has left the data
+            # path and given its GPU back, so that nobody waits under a watchdog while this runs.
+            enter("clock leg")
+            for buf in [b_[0] for b_ in d_batches] + [b_[2] for b_ in d_batches] + [d_digests]:
+                buf.free()
+            out["valu_roofline"] = valu_roofline_block(None if (a.no_clock_leg or collective != "nccl") else clock_leg(a.seed, a.maxlen, a.leaves_log2))
+            if not a.no_cpu_baseline:
+                enter("cpu baseline")
+                out["cpu_baseline"] = cpu_baseline_block()
         if world > 1 and collective == "nccl":
             enter("hip:all probe")
             out["hip_all_one_process_check"] = hip_all_check(timeout_s=60)

@@ -175,23 +175,6 @@ VKMR_API vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream s, 
 VKMR_API size_t vkmr_hip_sizes_scratch_bytes(uint32_t count);
 
 /*
- * TEXT -> PACKED BATCH, on the device.  Newline-separated text that already lies in device memory becomes what the
- * reference's input loop and Batch::Push build on the host one string at a time: every non-empty line is a string
- * (Input::Get, src/vkmr/Inputs.cpp:75-101: a line ends at '\n', '\r' is kept; run() skips empty lines,
- * src/vkmr/Vkmr.cpp:38-51), the strings lie back to back on word boundaries with zero padding from word 0 of data_dev,
- * and meta_dev[i] = {start word, size} (src/vkmr/Batches.cpp:64-121).  vkmr_hip_map_async takes the result as it is.
- *   text_dev     text_bytes bytes (below 4 GiB), 16-byte aligned, readable up to the next multiple of 16 plus 16; the
- *                text must END IN '\n' (append one to a last line that has none): what follows the last '\n' is ignored
- *   scratch_dev  vkmr_hip_split_scratch_bytes(text_bytes, meta_capacity) bytes
- *   result_dev   three words, written: [0] strings found, [1] words they take, [2] 0 -- or 1 when they do not fit
- *                meta_capacity entries / data_capacity_words words (then what was written is not to be used)
- */
-VKMR_API vkmr_status vkmr_hip_split_text_async(int dev, vkmr_stream s, const uint8_t* text_dev, uint32_t text_bytes, void* scratch_dev,
-                                               uint32_t* data_dev, uint64_t data_capacity_words, vkmr_metadata* meta_dev,
-                                               uint32_t meta_capacity, uint32_t* result_dev);
-VKMR_API size_t vkmr_hip_split_scratch_bytes(uint32_t text_bytes, uint32_t meta_capacity);
-
-/*
  * REDUCE, several slices at once: `nslices` consecutive slices of `capacity` digests
  * each (a power of two), the last holding `count_last` <= capacity, all reduced
  * through `height` levels by the same launches; roots_dev[k] receives slice k's
@@ -225,6 +208,21 @@ VKMR_API vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s,
                                           const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
                                           uint64_t index, void* scratch_dev,
                                           vkmr_digest* siblings_dev, vkmr_digest* root_dev);
+
+/*
+ * REDUCE + PROOFS in one pass -- the reference's to-do as it words it: "for an indicated leaf,
+ * allocate a buffer to hold and write out the intermediate values during reduction"
+ * (README.md:118-120).  Exactly vkmr_hip_reduce_async (same launches, same root) with the
+ * kernels' proof-writing instantiations: the lane that hashes the pair a path node belongs to
+ * stores the other node of that pair.  indices[0..k): leaf indices (< count), k <= 16, read on
+ * the host at call time.  siblings_dev[q * height + l] = sibling of indices[q]'s path node at
+ * level l, as vkmr_hip_proof_async defines it; no extra hash is computed, the reduction's time
+ * does not change measurably.  vkmr_hip_proof_async is kept as the independent cross-check.
+ */
+VKMR_API vkmr_status vkmr_hip_reduce_proofs_async(int dev, vkmr_stream s,
+                                                  const vkmr_digest* digests_dev, uint64_t count, uint32_t height,
+                                                  void* scratch_dev, vkmr_digest* root_dev,
+                                                  const uint64_t* indices, uint32_t k, vkmr_digest* siblings_dev);
 
 /*
  * One tree level per launch, one lane per pair: the reference's non-subgroup

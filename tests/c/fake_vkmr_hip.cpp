@@ -454,6 +454,39 @@ vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream, const vkmr_digest* digest
     return VKMR_OK;
 }
 
+vkmr_status vkmr_hip_reduce_proofs_async(int dev, vkmr_stream s, const vkmr_digest* digests, uint64_t count, uint32_t height, void* scratch,
+                                         vkmr_digest* root, const uint64_t* indices, uint32_t k, vkmr_digest* siblings)
+{
+    if (k == 0) return vkmr_hip_reduce_async(dev, s, digests, count, height, scratch, root);
+    if (!indices || !siblings || k > 16) return fail(VKMR_ERR_INVALID, "reduce_proofs: bad argument");
+    if (room_at(siblings) < (size_t)k * height * 32) return fail(VKMR_ERR_INVALID, "reduce_proofs: siblings are not device memory (or too small)");
+    const vkmr_status st = vkmr_hip_reduce_async(dev, s, digests, count, height, scratch, root);   // argument checks, injected failures, the root
+    if (st != VKMR_OK) return st;
+    std::vector<char> tmp(count > 128 ? 64 : 0);
+    for (uint32_t q = 0; q < k; ++q) {
+        if (indices[q] >= count) return fail(VKMR_ERR_INVALID, "reduce_proofs: index out of range");
+        // same sibling definition as vkmr_hip_proof_async; the double computes it the slow way, level by level
+        std::vector<uint32_t> nodes(8 * count);
+        memcpy(nodes.data(), digests, 32 * count);
+        uint64_t n = count, p = indices[q];
+        for (uint32_t lv = 0; lv < height; ++lv) {
+            const uint64_t o = ((p ^ 1ull) < n) ? (p ^ 1ull) : p;
+            memcpy(siblings[(size_t)q * height + lv].data, nodes.data() + 8 * o, 32);
+            const uint64_t pairs = (n + 1) / 2;
+            for (uint64_t i = 0; i < pairs; ++i) {
+                const uint32_t* l = nodes.data() + 16 * i;
+                const uint32_t* r = (2 * i + 1 < n) ? l + 8 : l;
+                uint32_t h[8];
+                vkmr::cpu_sha256d_pair(l, r, h);
+                memcpy(nodes.data() + 8 * i, h, 32);
+            }
+            n = pairs;
+            p >>= 1;
+        }
+    }
+    return VKMR_OK;
+}
+
 vkmr_status vkmr_hip_comm_create_id(void* id)
 {
     if (!id) return fail(VKMR_ERR_INVALID, "comm_create_id");

@@ -91,7 +91,18 @@ def main():
     p.add_argument("--seeds", type=int, nargs="*", default=list(range(42, 50)))
     p.add_argument("--count-log2", type=int, default=26)
     p.add_argument("--maxlen", type=int, default=127)
+    p.add_argument("--config5", action="store_true",
+                   help="only add rec['config5']: the reference's root of `rndm 42 2^24 4096` (BASELINE configs[4]; 34 GB of text, about 40 minutes)")
     a = p.parse_args()
+    if a.config5:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all", "ref"], stdout=subprocess.DEVNULL)
+        rec = json.load(open(OUT))
+        _, r = run_one(42, 1 << 24, 4096)
+        rec["config5"] = dict(r, generator="rndm 42 16777216 4096",
+                              about="BASELINE configs[4] at full size, printed by the reference CPU-serial path; bench.py's config5_full leg checks its root against this")
+        with open(OUT, "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
+        return
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all", "ref"], stdout=subprocess.DEVNULL)
     count = 1 << a.count_log2
     rec = {}

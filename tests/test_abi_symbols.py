@@ -97,6 +97,8 @@ def test_docs_name_only_entry_points_that_exist():
     """INTEGRATION.md, DESIGN.md and README.md may only name `vkmr_hip_*` entry points the header declares (or host-library
     helpers, `vkmr_host_*`): stale names in the binding guide would send a maintainer looking for functions that are gone."""
     declared = set(declared_symbols())
+    # the experiments build's entry points (include/vkmr_hip_experiments.h) may be named too -- as what they are
+    declared |= set(re.findall(r"VKMR_API\s+[\w\s\*]+?\b(vkmr_hip_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "vkmr_hip_experiments.h")).read()))
     for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
         text = open(os.path.join(ROOT, doc)).read()
         for name in set(re.findall(r"\b(vkmr_hip_[a-z0-9_]+)\b", text)):

@@ -93,3 +93,45 @@ def test_bench_secondary_blocks_agree_with_the_timed_root(fake_lib, oracle):
     assert d["root"] == oracle.hex(oracle_root(oracle, 42, 1 << 12))
     assert d["pipeline_pcie_inclusive"]["root_matches"] is True
     assert d["two_stream_overlap"]["roots_match"] is True
+
+
+def test_an_n_rank_line_is_as_complete_as_the_one_rank_line(fake_lib, oracle):
+    """with N > 1 rank 0 still reports `roofline`, `valu_roofline` and `cpu_baseline` (the reference's CPU
+    path on rank 0's stream, labelled as 1/N of the workload) -- after every rank has left the data path.  Eight ranks, the
+    script's own launcher, the labelled gloo rehearsal through the fake ABI."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["VKMR_HIP_LIB"] = fake_lib
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rehearse-gloo", "--leaves-log2", "10", "--steps", "1", "--warmup", "1",
+                        "--no-pipeline", "--no-long-strings"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:].decode()
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in REQUIRED + ["roofline_reduce", "valu_roofline", "cpu_baseline"]:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["config"]["leaves_total"] == 8 << 10 and len(d["sub_roots"]) == 8
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and "1/8 of the workload" in cb["sample"] and cb["leaves"] == 1 << 10
+    assert cb["root_matches_gpu"] is True                      # rank 0's sub-tree root IS the root of rank 0's stream
+    subs = np.stack([oracle.reduce_height(_leaves(oracle, 42 + k, 1 << 10), 10) for k in range(8)])
+    assert d["root"] == oracle.hex(oracle.root(subs))
+
+
+def test_what_an_eight_gpu_line_says_about_its_gather_and_its_golden_roots():
+    """The parts of an 8-GPU line that cannot run here (RCCL, 2^29 leaves), as the functions that write them: the gather is
+    named as ONE RCCL all-gather through the C ABI, the workload as BASELINE configs[3], and the root is checked against the
+    combination of the eight reference-made sub-roots in rank order (tests/golden/big_roots.json) -- a wrong order or a wrong
+    sub-root is reported as such."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert "ncclAllGather" in bench.gather_label(True, True) and "C ABI" in bench.gather_label(True, True)
+    assert "gloo" in bench.gather_label(True, False) and bench.gather_label(False, False) is None
+    assert "configs[3]" in bench.workload_label(42, 26, 127, 8) and "configs[2]" in bench.workload_label(42, 26, 127, 1)
+    golden = bench.golden_big_roots(26, 127)
+    assert golden and set(golden["combined"]) >= {str(k) for k in range(1, 9)}
+    subs = [golden["sub_roots"][str(42 + r)]["root"] for r in range(8)]
+    assert bench.check_against_golden(golden, 42, 8, golden["combined"]["8"], subs) == (True, True)
+    assert bench.check_against_golden(golden, 42, 8, golden["combined"]["8"], subs[::-1]) == (True, False)
+    assert bench.check_against_golden(golden, 42, 8, golden["combined"]["4"], subs) == (False, True)
+    assert bench.check_against_golden(golden, 42, 4, golden["combined"]["4"], subs[:4]) == (True, True)
+    assert bench.check_against_golden(None, 42, 8, "", []) == (None, None)

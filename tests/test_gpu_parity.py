@@ -52,6 +52,8 @@ def test_metadata_from_sizes(gpu):
 
 def _split_on_gpu(gpu, text, meta_capacity=None, data_capacity_words=None):
     import vk_merkle_roots_amd as vk
+    from vk_merkle_roots_amd import _abi
+    exp = _abi.experiments_lib()      # the splitter lives in the experiments build since round 4 (include/vkmr_hip_experiments.h)
     n = len(text)
     lines = text.count(b"\n")
     meta_capacity = meta_capacity if meta_capacity is not None else max(1, lines)
@@ -60,10 +62,10 @@ def _split_on_gpu(gpu, text, meta_capacity=None, data_capacity_words=None):
     d_text = gpu.upload(padded)
     d_data = gpu.alloc(4 * data_capacity_words + 64)
     d_meta = gpu.alloc(8 * meta_capacity + 16)
-    d_scratch = gpu.alloc(gpu.lib.vkmr_hip_split_scratch_bytes(n, meta_capacity))
+    d_scratch = gpu.alloc(exp.vkmr_hip_split_scratch_bytes(n, meta_capacity))
     d_result = gpu.alloc(16)
     vk.check(gpu.lib.vkmr_hip_memset_async(gpu.index, gpu.stream, d_data.ptr, 0xCD, 4 * data_capacity_words + 64), "memset")
-    vk.check(gpu.lib.vkmr_hip_split_text_async(gpu.index, gpu.stream, d_text.ptr, n, d_scratch.ptr, d_data.ptr, data_capacity_words, d_meta.ptr, meta_capacity,
+    vk.check(exp.vkmr_hip_split_text_async(gpu.index, gpu.stream, d_text.ptr, n, d_scratch.ptr, d_data.ptr, data_capacity_words, d_meta.ptr, meta_capacity,
                                                d_result.ptr), "split")
     strings, words, status = (int(x) for x in gpu.download(d_result, 12))
     meta = gpu.download(d_meta, 8 * min(strings, meta_capacity)).reshape(-1, 2) if strings else np.zeros((0, 2), np.uint32)
@@ -385,6 +387,46 @@ def test_proofs_fold_to_the_root(gpu, oracle):
                     if q >= len(levels[l]):
                         q = p
                     assert (sib[l] == levels[l][q]).all(), (n, height, index, l)
+
+
+def test_proofs_written_during_the_reduction_equal_the_recomputed_ones(gpu, oracle):
+    """vkmr_hip_reduce_proofs_async writes, while the root is computed, the same sibling arrays that
+    vkmr_hip_proof_async obtains by reducing every sibling sub-tree again -- for K = 1 and K = 8 (and 16) leaves, on the same
+    cases as the test above and on sizes that go through every kernel of the schedule (bulk passes, collapses, tail, levels
+    above a lone node), with the same root as the plain reduction."""
+    import vk_merkle_roots_amd as vk
+    h = vk.host_lib()
+    rng = np.random.default_rng(13)
+    cases = [(1, 1), (2, 1), (3, 2), (5, 3), (8, 3), (9, 4), (100, 7), (129, 8), (1000, 10), (1000, 14), (4097, 13), (70001, 17), (300000, 19),
+             (1 << 20, 20), ((1 << 20) + 77, 21), (3000001, 22), (1 << 22, 23)]
+    for n, height in cases:
+        leaves = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32)
+        d_in = gpu.upload(leaves)
+        want_root = gpu.reduce_digests(leaves, height)
+        fixed = sorted({0, n - 1, n // 2, (n * 2) // 3, max(0, n - 2)})
+        for K in (1, 8, 16):
+            idx = (fixed + [int(x) for x in rng.integers(0, n, size=16)])[:K] if K > 1 else [fixed[-1]]
+            sib, root = gpu.reduce_with_proofs(d_in, n, height, idx)
+            assert (root == want_root).all(), (n, height, K)
+            for q, index in enumerate(idx):
+                folded = np.zeros(8, dtype=np.uint32)
+                h.vkmr_host_cpu_fold_proof(leaves[index].ctypes.data, index, np.ascontiguousarray(sib[q]).ctypes.data, height, folded.ctypes.data)
+                assert (folded == want_root).all(), (n, height, K, index)
+        # sibling by sibling against the recomputing form, on a few leaves (it costs a reduction per leaf)
+        for index in fixed[:3] if n > 100000 else fixed:
+            want_sib, _ = gpu.proof(d_in, n, height, index)
+            sib, _ = gpu.reduce_with_proofs(d_in, n, height, [index])
+            assert (sib[0] == want_sib).all(), (n, height, index)
+        d_in.free()
+
+
+def test_reduce_with_proofs_rejects_bad_arguments(gpu):
+    import vk_merkle_roots_amd as vk
+    d = gpu.alloc(32 * 8)
+    with pytest.raises(vk.VkmrError):
+        gpu.reduce_with_proofs(d, 8, 3, [8])
+    with pytest.raises(vk.VkmrError):
+        gpu.reduce_with_proofs(d, 8, 3, list(range(8)) * 3)      # 24 > 16 proofs per reduction
 
 
 def test_proof_rejects_bad_index(gpu):

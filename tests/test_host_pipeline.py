@@ -24,9 +24,7 @@ def _newer(target, sources):
     return os.path.exists(target) and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in sources)
 
 
-@pytest.fixture(scope="session")
-def fake_vkmr(native):
-    """(path of the sanitized vkmr linked against the fake ABI, base environment)."""
+def _build_fake_vkmr(native, defines=(), suffix=""):
     os.makedirs(OUT, exist_ok=True)
     inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", CSRC]
     lib = os.path.join(OUT, "libvkmr_hip.so")
@@ -34,16 +32,29 @@ def fake_vkmr(native):
     hdrs = [os.path.join(ROOT, "include", "vkmr_hip.h"), os.path.join(CSRC, "reduce_plan.hpp")]
     if not _newer(lib, lib_src + hdrs):
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-shared", "-fPIC"] + SAN + inc + lib_src + ["-o", lib])
-    exe = os.path.join(OUT, "vkmr_asan")
+    exe = os.path.join(OUT, "vkmr_asan" + suffix)
     files = ["vkmr_main.cpp", "cpu_sha256d.cpp", "hip_sha256d.cpp", "inputs.cpp", "batches.cpp", "slices.cpp", "mappings.cpp", "reductions.cpp",
              "stream_pack.cpp"]
     srcs = [os.path.join(HOST, f) for f in files]
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + hdrs + [lib]
     if not _newer(exe, deps):
-        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-pthread"] + SAN + inc + srcs + ["-o", exe, "-L", OUT, "-lvkmr_hip", "-Wl,-rpath," + OUT])
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-pthread"] + SAN + list(defines) + inc + srcs + ["-o", exe, "-L", OUT, "-lvkmr_hip", "-Wl,-rpath," + OUT])
     env = {k: v for k, v in os.environ.items() if not k.startswith("VKMR_") and k != "LD_PRELOAD"}
     env.update(LD_LIBRARY_PATH=OUT, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     return exe, env
+
+
+@pytest.fixture(scope="session")
+def fake_vkmr(native):
+    """(path of the sanitized vkmr linked against the fake ABI, base environment)."""
+    return _build_fake_vkmr(native)
+
+
+@pytest.fixture(scope="session")
+def fake_vkmr_experiments(native):
+    """The same front end built with -DVKMR_EXPERIMENTS: the host side of the paths that are measured but not shipped
+    (the device-split mode, include/vkmr_hip_experiments.h)."""
+    return _build_fake_vkmr(native, ["-DVKMR_EXPERIMENTS"], "_exp")
 
 
 def run(fake_vkmr, backend, stream, **knobs):
@@ -194,8 +205,9 @@ def test_hip_all_deals_one_slice_per_device_when_the_input_size_is_known(fake_vk
     {"VKMR_PACK_THREADS": 7, "VKMR_INPUT_SPAN_MB": 3, "VKMR_SLICE_LOG2": 18, "VKMR_MAX_INFLIGHT": 1},
     {"VKMR_PACK_THREADS": 1, "VKMR_INPUT_SPAN_MB": 5, "VKMR_BATCH_MB": 4},                            # the span does not fit the batch's text area
 ])
-def test_text_split_on_the_device(fake_vkmr, native, golden, oracle, knobs, tmp_path):
-    """VKMR_DEVICE_SPLIT=1: spans of 1 MiB and more are copied into pinned memory as they are (their lines counted on the
+def test_text_split_on_the_device(fake_vkmr_experiments, native, golden, oracle, knobs, tmp_path):
+    """EXPERIMENTS BUILD (the mode measured no gain and is not in the product: the product front end ignores the knob, see the
+    last lines).  VKMR_DEVICE_SPLIT=1: spans of 1 MiB and more are copied into pinned memory as they are (their lines counted on the
     way), split into strings by vkmr_hip_split_text_async, and mapped; spans that do not qualify take the host packer.  The
     golden 2^20-string stream from a file and through a pipe, and a stream with runs of empty lines, CRs and no final
     newline, for thread counts that do not divide the spans, spans larger than the batch, and slices smaller than a span:
@@ -207,7 +219,7 @@ def test_text_split_on_the_device(fake_vkmr, native, golden, oracle, knobs, tmp_
     path = tmp_path / "g3.txt"
     path.write_bytes(stream)
     for body, want, via_file in ((stream, (s["root"], s["items"], s["bytes"]), True), (stream, (s["root"], s["items"], s["bytes"]), False), (odd, want_odd, False)):
-        exe, env = fake_vkmr
+        exe, env = fake_vkmr_experiments
         env = dict(env, VKMR_DEVICE_SPLIT="1", VKMR_FAKE_COUNT_FORMS="1", **{k: str(v) for k, v in knobs.items()})
         if via_file:
             with open(path, "rb") as f:
@@ -219,6 +231,16 @@ def test_text_split_on_the_device(fake_vkmr, native, golden, oracle, knobs, tmp_
         assert (m["root"], int(m["items"]), int(m["bytes"])) == tuple(want), (knobs, via_file)
         split = [l for l in r.stderr.decode().splitlines() if l.startswith("fake: texts split on the device")]
         assert split and int(re.findall(r"(\d+)", split[-1])[0]) > 0, r.stderr[-300:]
+
+
+def test_the_product_front_end_has_no_device_split_mode(fake_vkmr, native, golden):
+    """an opt-in mode that measured no gain is not a product feature.  The product build of the front end does
+    not read VKMR_DEVICE_SPLIT: same root, and the device-side splitter is never called."""
+    s = golden["streams"]["G3_rndm_42_1048576_127"]
+    r, out, m = run(fake_vkmr, "hip:0", stream_of(native, s), VKMR_DEVICE_SPLIT=1, VKMR_FAKE_COUNT_FORMS=1)
+    assert m["root"] == s["root"]
+    split = [l for l in r.stderr.decode().splitlines() if l.startswith("fake: texts split on the device")]
+    assert not split or int(re.findall(r"(\d+)", split[-1])[0]) == 0
 
 
 def test_batches_cross_as_sizes_or_as_entries(fake_vkmr, native, oracle):
@@ -355,6 +377,33 @@ def test_merkle_proof_of_a_leaf_folds_to_the_printed_root(fake_vkmr, native, gol
         assert fold_proof(proof) == s["root"], (index, ndev, shape)
     r, out, m = run(fake_vkmr, "hip:0", stream, VKMR_PROOF_INDEX=1000, **shape)      # one past the last leaf
     assert m["root"] == s["root"] and any("is not in the stream" in l for l in out)
+
+
+def test_several_merkle_proofs_in_one_run(fake_vkmr, native, golden):
+    """VKMR_PROOF_INDEX=a,b,c: the proofs are written by the reductions that hold the leaves (and by the combine above them);
+    each block of lines folds to the root; a leaf beyond the stream is reported, not invented."""
+    s = golden["streams"]["G2_rndm_1712489279_1024_127"]
+    stream = stream_of(native, s)
+    for shape in ({}, {"VKMR_SLICE_LOG2": 6}, {"VKMR_SLICE_LOG2": 5, "VKMR_FAKE_DEVICES": 3}):
+        backend = "hip:all" if "VKMR_FAKE_DEVICES" in shape else "hip:0"
+        r, out, m = run(fake_vkmr, backend, stream, VKMR_PROOF_INDEX="0,63,64,1023,517,5000,64", **shape)
+        assert m["root"] == s["root"]
+        proof = [l for l in out if l.startswith("proof: ")]
+        blocks, cur = [], []
+        for l in proof:
+            if l.startswith("proof: leaf "):
+                if cur:
+                    blocks.append(cur)
+                cur = [l]
+            else:
+                cur.append(l)
+        blocks.append(cur)
+        assert [b[0].split()[2] for b in blocks] == ["0", "63", "64", "1023", "517", "5000", "64"]
+        for b in blocks:
+            if b[0].split()[2] == "5000":
+                assert "is not in the stream" in b[0] and len(b) == 1
+            else:
+                assert fold_proof(b) == s["root"], (shape, b[0])
 
 
 def test_merkle_proof_of_a_lone_leaf(fake_vkmr):

@@ -37,9 +37,6 @@ SIGNATURES = {
     "vkmr_hip_stream_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vkmr_hip_metadata_from_sizes_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_sizes_scratch_bytes": (C.c_size_t, [C.c_uint32]),
-    "vkmr_hip_split_text_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
-                                            C.c_void_p]),
-    "vkmr_hip_split_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "vkmr_hip_warm_up": (C.c_int, [C.c_int, C.c_void_p, C.c_uint, C.c_size_t]),
     "vkmr_hip_stream_destroy": (C.c_int, [C.c_int, C.c_void_p]),
     "vkmr_hip_stream_sync": (C.c_int, [C.c_int, C.c_void_p]),
@@ -58,6 +55,8 @@ SIGNATURES = {
     "vkmr_hip_reduce_slices_scratch_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32]),
     "vkmr_hip_proof_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "vkmr_hip_reduce_proofs_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_void_p]),
     "vkmr_hip_reduce_levels_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vkmr_hip_reduce_levels_scratch_bytes": (C.c_size_t, [C.c_uint64]),
     "vkmr_hip_combine_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -95,6 +94,13 @@ HOST_SIGNATURES = {
     "vkmr_host_pack_prefix": (None, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
 }
 
+# include/vkmr_hip_experiments.h: exported by the experiments build only (build/ab/libexp.so); bound when present
+EXPERIMENT_SIGNATURES = {
+    "vkmr_hip_split_text_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                            C.c_void_p]),
+    "vkmr_hip_split_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+}
+
 _lib = None
 _host = None
 
@@ -111,6 +117,16 @@ def _bind(lib, table):
         fn.restype = res
         fn.argtypes = args
     return lib
+
+
+def experiments_lib(path=None):
+    """The experiments build (include/vkmr_hip_experiments.h), loaded BESIDE whatever lib() is: same process, same HIP
+    runtime, so device pointers and streams of the one are good in the other.  Tests of the non-shipped entry points only."""
+    from .build import EXP_LIB
+    path = path or EXP_LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: vk_merkle_roots_amd.build.build_experiments()")
+    return _bind(C.CDLL(path), EXPERIMENT_SIGNATURES)   # RTLD_LOCAL: its other symbols must not shadow the product library's
 
 
 def lib():

@@ -28,7 +28,7 @@ STAMPS_LIB = os.path.join(PKG, "libvkmr_hip_stamps.so")
 EXP_LIB = os.path.join(ROOT, "build", "ab", "libexp.so")
 ARCH = "gfx950"
 SPLIT_ADD3_EVERY = 4   # isa_prio_pass: every 4th v_add3_u32 becomes two v_add_u32 (balances the two issue slots: -1.4 %, profiles/r03_ab_add3_split.txt)
-LATENCY_BOUND_KERNELS = ("reduce_collapse_kernel", "reduce_tail_kernel")   # one wavefront per SIMD: left as hipcc emits them (collapse: 113 vs 140 us with the pass, profiles/r03_reduce_top_kernels.txt)
+LATENCY_BOUND_KERNELS = ("reduce_collapse_kernel", "reduce_tail_kernel", "reduce_collapse_proofs_kernel", "reduce_tail_proofs_kernel")   # one wavefront per SIMD: left as hipcc emits them (collapse: 113 vs 140 us with the pass, profiles/r03_reduce_top_kernels.txt)
 ROTATE_LEVEL = None    # isa_prio_pass: priority of v_alignbit_b32 when it differs from the other complex instructions' (1)
 PRIO_GAP = 0    # isa_prio_pass: complex-instruction runs separated by at most this many simple instructions are merged
 

@@ -14,8 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/vkmr_hip.h"
-#include "meta_kernels.hpp"
+#include "../../../include/vkmr_hip.h"
+#include "../meta_kernels.hpp"
 
 #define VKMR_SPLIT_THREADS 256
 #define VKMR_SPLIT_BLOCK (VKMR_SPLIT_THREADS * 16)   // text bytes per workgroup

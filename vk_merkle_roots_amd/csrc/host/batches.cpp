@@ -10,6 +10,9 @@
 #include "timing.hpp"
 
 #include "stream_pack.hpp"
+#ifdef VKMR_EXPERIMENTS
+#include "vkmr_hip_experiments.h"
+#endif
 
 namespace vkmr {
 
@@ -304,6 +307,7 @@ bool Batches::Allocate(size_t words, size_t count, Buffers* out)
     }
     *out = {static_cast<uint32_t*>(h1), static_cast<vkmr_metadata*>(h2), static_cast<uint32_t*>(d1), static_cast<vkmr_metadata*>(d2), words, count,
             static_cast<uint16_t*>(h3), static_cast<uint16_t*>(d3), d4, nullptr, nullptr, nullptr, nullptr};
+#ifdef VKMR_EXPERIMENTS
     if (m_device_split && words * 4 < 0xFFFFFFE0ull) {   // the splitter's text area, scratch and result words; without them the batch simply cannot hold text
         void *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr;
         const bool ok2 = vkmr_hip_device_alloc(m_dev, words * 4 + 64, &t1) == VKMR_OK &&
@@ -315,6 +319,7 @@ bool Batches::Allocate(size_t words, size_t count, Buffers* out)
             vkmr_hip_device_free(m_dev, t1); vkmr_hip_device_free(m_dev, t2); vkmr_hip_device_free(m_dev, t3); vkmr_hip_host_free(t4);
         }
     }
+#endif
     return true;
 }
 

@@ -31,9 +31,20 @@ HipConfig HipConfig::FromEnv()
     if (const char* e = getenv("VKMR_MAX_INFLIGHT")) c.max_inflight = (size_t)atol(e);
     if (const char* e = getenv("VKMR_SLICE_BUDGET")) c.slice_budget = (size_t)atol(e);
     if (const char* e = getenv("VKMR_VERBOSE")) c.verbose = atoi(e) != 0;
-    if (const char* e = getenv("VKMR_PROOF_INDEX")) c.proof_index = atoll(e);
+    if (const char* e = getenv("VKMR_PROOF_INDEX")) {   // "a" or "a,b,c": leaves to prove
+        for (const char* p = e; *p;) {
+            char* end = nullptr;
+            const long long v = strtoll(p, &end, 10);
+            if (end == p) break;
+            if (v >= 0) c.proof_indices.push_back((unsigned long long)v);
+            p = (*end == ',') ? end + 1 : end;
+            if (*end && *end != ',') break;
+        }
+    }
     if (const char* e = getenv("VKMR_SEND_METADATA")) c.send_sizes = atoi(e) == 0;
-    if (const char* e = getenv("VKMR_DEVICE_SPLIT")) c.device_split = atoi(e) != 0;
+#ifdef VKMR_EXPERIMENTS
+    if (const char* e = getenv("VKMR_DEVICE_SPLIT")) c.device_split = atoi(e) != 0;   // experiments build only (include/vkmr_hip_experiments.h)
+#endif
     if (const char* e = getenv("VKMR_PACK_STREAM")) c.pack_stream = atoi(e) < 0 ? -1 : (atoi(e) != 0);
     if (const char* e = getenv("VKMR_PACK_THREADS")) c.pack_threads = (unsigned)atoi(e);
     if (c.pack_threads == 0) {
@@ -250,7 +261,7 @@ bool HipSha256D::Instance::EnsureGeometry(const char* first_span, size_t len)
     m_slices = Slices(m_device_ids, capacity, m_cfg.slice_budget ? m_cfg.slice_budget : m_cfg.max_inflight + 1);
     m_reductions = Reductions::New(m_device_ids, capacity, m_cfg.verbose);
     if (!m_reductions->Ok()) m_ok = false;   // reported by Reductions::New
-    if (m_cfg.proof_index >= 0) m_reductions->RequestProof((uint64_t)m_cfg.proof_index);
+    for (unsigned long long leaf : m_cfg.proof_indices) m_reductions->RequestProof((uint64_t)leaf);
     return m_ok;
 }
 
@@ -443,6 +454,7 @@ bool HipSha256D::Instance::Add(const char* bytes, size_t size)
     return m_slices.Current().Reserve(1);
 }
 
+#ifdef VKMR_EXPERIMENTS
 // The device-split path (HipConfig::device_split).  The host's part is one pass: the span's bytes into the batch's pinned
 // text area (fork-join, equal byte ranges -- no line boundaries needed) with its newlines counted, so that the slice and
 // the caller's tally know how many strings there are before the device has seen a byte.
@@ -494,6 +506,7 @@ size_t HipSha256D::Instance::PushTextForDevice(const char* text, size_t len, boo
     }
     return take;
 }
+#endif   // VKMR_EXPERIMENTS
 
 // Bulk ingest: whole spans of lines are packed straight into the pinned batch
 // (memchr + memcpy per line, no per-line call or temporary), with the same batch/slice
@@ -527,6 +540,7 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
                 if (!MapCurrent() || !NewBatch(dev)) return (m_ok = false);
             }
         }
+#ifdef VKMR_EXPERIMENTS
         if (m_cfg.device_split && len - pos >= ((size_t)1 << 20)) {
             // text for the device to split: into an empty batch (what the host packer left in the current one goes out first)
             if (!m_batch.Empty()) {
@@ -543,6 +557,7 @@ bool HipSha256D::Instance::AddLines(const char* buf, size_t len, bool final, Tal
                 continue;
             }
         }
+#endif
         Slice& slice = m_slices.Current();
         PackResult r = m_batch.PushLinesParallel(buf + pos, len - pos, final, slice.Available(), *m_pool, m_words_per_byte);
         if (r.consumed >= (1u << 20)) m_words_per_byte = (double)r.words / (double)r.consumed;

@@ -48,7 +48,7 @@ struct HipConfig {
     bool device_split = false;       // VKMR_DEVICE_SPLIT=1: large spans of text cross PCIe as they are and are split into strings on the device
                                      // (vkmr_hip_split_text_async); the host copies them into pinned memory and counts their lines, nothing else.
                                      // Spans that do not qualify (short, or more strings than the slice has room for) take the host packer
-    long long proof_index = -1;      // >= 0: also produce the Merkle proof of that leaf (0-based, stream order; README.md:118-120)
+    std::vector<unsigned long long> proof_indices;   // also produce the Merkle proofs of these leaves (0-based, stream order; at most 16; README.md:118-120)
     bool verbose = false;            // per-op log lines like the reference prints
     static HipConfig FromEnv();      // VKMR_SLICE_LOG2, VKMR_BATCH_MB / VKMR_BATCH_BYTES, VKMR_BATCH_MAX_MB, VKMR_MAX_INFLIGHT,
                                      // VKMR_SLICE_BUDGET, VKMR_PACK_THREADS, VKMR_SEND_METADATA, VKMR_PACK_STREAM, VKMR_DEVICE_SPLIT, VKMR_PROOF_INDEX, VKMR_VERBOSE
@@ -94,7 +94,7 @@ public:
     out_type RootOfStaged();
 
     bool Ok() const { return m_ok; }
-    // "proof: ..." lines of the requested Merkle proof (cfg.proof_index), valid after Root().
+    // "proof: ..." lines of the requested Merkle proof (cfg.proof_indices), valid after Root().
     std::vector<std::string> ProofLines() const { return m_reductions ? m_reductions->ProofLines() : std::vector<std::string>(); }
 
 private:
@@ -107,7 +107,9 @@ private:
     PerDevice& Dev(int dev);
     // The device-split path of AddLines: text[0, len) (whole lines; `final`: the last may lack its newline) into the current,
     // empty, batch as raw text.  Returns the bytes taken (0: this span goes through the host packer instead).
-    size_t PushTextForDevice(const char* text, size_t len, bool final, Tally* tally);
+#ifdef VKMR_EXPERIMENTS
+    size_t PushTextForDevice(const char* text, size_t len, bool final, Tally* tally);   // device-split path: experiments build only
+#endif
     void StartPrefetch();                                // the first device's batches start being pinned on its pool's helper thread
     bool EnsureGeometry(const char* first_span, size_t len);   // slices and reductions exist from the first string on
     uint32_t ChooseSliceLog2(const char* first_span, size_t len, std::string* why) const;

@@ -4,6 +4,9 @@
 #include <iostream>
 
 #include "ops.hpp"
+#ifdef VKMR_EXPERIMENTS
+#include "vkmr_hip_experiments.h"
+#endif
 #include "timing.hpp"
 
 namespace vkmr {
@@ -42,16 +45,19 @@ public:
             return VKMR_ERR_HIP;
         }
         HipResult r = vkmr_hip_event_record(m.dev, m.begin, copy_stream);
+#ifdef VKMR_EXPERIMENTS
         if (batch.TextBytes() > 0) {
-            // raw text: it crosses as it is, the device splits it into the packed layout in the batch's landing zone and
-            // says what it found (checked when the mapping retires)
+            // (experiments build) raw text: it crosses as it is, the device splits it into the packed layout in the batch's
+            // landing zone and says what it found (checked when the mapping retires)
             timing::Scope ts(timing::MAP_COPIES);
             if (r == VKMR_OK) r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceText(), batch.TextArea(), batch.TextBytes());
             if (r == VKMR_OK)
                 r = vkmr_hip_split_text_async(m.dev, copy_stream, batch.DeviceText(), (uint32_t)batch.TextBytes(), batch.DeviceSplitScratch(), batch.DeviceData(),
                                               batch.CapacityWords(), batch.DeviceMeta(), (uint32_t)batch.CapacityCount(), batch.DeviceSplitResult());
             if (r == VKMR_OK) r = vkmr_hip_memcpy_d2h_async(m.dev, copy_stream, batch.HostSplitResult(), batch.DeviceSplitResult(), 3 * sizeof(uint32_t));
-        } else {
+        } else
+#endif
+        {
             timing::Scope ts(timing::MAP_COPIES);
             if (r == VKMR_OK)
                 r = vkmr_hip_memcpy_h2d_async(m.dev, copy_stream, batch.DeviceData(), batch.HostData(), batch.Words() * 4);

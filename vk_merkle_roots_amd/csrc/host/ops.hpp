@@ -74,10 +74,10 @@ public:
     // the hex root ("" on failure or when nothing was reduced).
     virtual ISha256D::out_type WaitFor() = 0;
 
-    // Merkle proof (the reference's to-do, README.md:118-120): asks for the authentication path of leaf
-    // `leaf_index` (0-based, stream order).  The siblings inside the leaf's slice are computed when that slice is
-    // reduced (vkmr_hip_proof_async on the reduction's stream, before the slice's memory is re-used), those above
-    // it over the slice roots at WaitFor().  ProofLines() then gives "proof: ..." lines, bottom level first.
+    // Merkle proofs (the reference's to-do, README.md:118-120): asks for the authentication path of leaf `leaf_index`
+    // (0-based, stream order); up to 16 leaves per run.  The siblings inside a leaf's slice are written BY the reduction of
+    // that slice as it hashes them (vkmr_hip_reduce_proofs_async), those above it by the combine of the slice roots at
+    // WaitFor().  ProofLines() then gives, per leaf in request order, "proof: ..." lines, bottom level first.
     virtual void RequestProof(uint64_t leaf_index) = 0;
     virtual std::vector<std::string> ProofLines() const = 0;
 

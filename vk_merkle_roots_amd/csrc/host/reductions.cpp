@@ -75,7 +75,7 @@ public:
             vkmr_hip_host_free(d.roots_host);
         }
         if (m_comm) vkmr_hip_comm_destroy(m_comm);
-        if (m_proof_dev) vkmr_hip_device_free(m_proof_dev_device, m_proof_dev);
+        for (auto& pd : m_proof_dev) vkmr_hip_device_free(pd.first, pd.second);
         vkmr_hip_host_free(m_proof_host);
     }
 
@@ -105,27 +105,33 @@ public:
 
     void RequestProof(uint64_t leaf_index) override
     {
-        m_proof_wanted = true;
-        m_proof_leaf = leaf_index;
+        if (m_proofs.size() >= kMaxProofs) {
+            std::cerr << "At most " << kMaxProofs << " Merkle proofs per run: leaf " << leaf_index << " is not proved." << std::endl;
+            return;
+        }
+        ProofReq r;
+        r.leaf = leaf_index;
+        r.host_at = m_proofs.size() * kProofRecord;
+        m_proofs.push_back(r);
     }
 
     std::vector<std::string> ProofLines() const override
     {
         std::vector<std::string> lines;
-        if (!m_proof_wanted) return lines;
-        if (!m_proof_done) {
-            lines.push_back("proof: leaf " + std::to_string(m_proof_leaf) + " is not in the stream (or the run failed)");
-            return lines;
-        }
-        lines.push_back("proof: leaf " + std::to_string(m_proof_leaf) + " " + digest_words_to_hex(m_proof_leaf_digest.data));
-        // bit l of the node index tells on which side the path node sits at level l; inside the slice the node index is the
-        // leaf's offset, above it the slice's position
-        uint64_t idx = m_proof_offset;
-        for (size_t l = 0; l < m_proof_path.size(); ++l) {
-            if (l == m_proof_slice_levels) idx = m_proof_slice_pos;
-            const bool path_is_right = (idx >> (l < m_proof_slice_levels ? l : l - m_proof_slice_levels)) & 1ull;
-            lines.push_back("proof: level " + std::to_string(l) + (path_is_right ? " sibling-on-left " : " sibling-on-right ") +
-                            digest_words_to_hex(m_proof_path[l].data));
+        for (const ProofReq& r : m_proofs) {
+            if (!r.done) {
+                lines.push_back("proof: leaf " + std::to_string(r.leaf) + " is not in the stream (or the run failed)");
+                continue;
+            }
+            lines.push_back("proof: leaf " + std::to_string(r.leaf) + " " + digest_words_to_hex(r.leaf_digest.data));
+            // bit l of the node index tells on which side the path node sits at level l; inside the slice the node index is the
+            // leaf's offset, above it the slice's position
+            for (size_t l = 0; l < r.path.size(); ++l) {
+                const uint64_t idx = l < r.slice_levels ? r.offset : (uint64_t)(r.slice_number - 1);
+                const bool path_is_right = (idx >> (l < r.slice_levels ? l : l - r.slice_levels)) & 1ull;
+                lines.push_back("proof: level " + std::to_string(l) + (path_is_right ? " sibling-on-left " : " sibling-on-right ") +
+                                digest_words_to_hex(r.path[l].data));
+            }
         }
         return lines;
     }
@@ -233,29 +239,44 @@ private:
         return st;
     }
 
-    // The part of the proof that lies inside the leaf's slice: `height` siblings and the leaf digest, computed on the
-    // reduction's stream right before the reduction (same scratch: the stream serialises them) and copied to the host.
-    HipResult ProveInSlice(PerDevice& d, const slice_type& slice, uint32_t height, void* scratch, vkmr_stream stream)
+    // The reduction of a slice that holds leaves whose proofs were asked for: the same launches, with the kernels that write
+    // the siblings of those leaves' path nodes as they hash them (vkmr_hip_reduce_proofs_async; the reference's to-do,
+    // README.md:118-120: "write out the intermediate values during reduction").  The leaf digests and the sibling rows
+    // are copied to the host on the reduction's stream.
+    HipResult ReduceAndProve(PerDevice& d, const slice_type& slice, uint32_t height, void* scratch, vkmr_stream stream, vkmr_digest* root_dev)
     {
-        m_proof_slice_seen = true;
-        m_proof_offset = m_proof_leaf % m_capacity;
-        if (m_proof_offset >= slice.Count()) return VKMR_OK;   // past the end of the stream: reported by ProofLines()
-        m_proof_slice_levels = height;
-        m_proof_slice_number = slice.Number();
+        std::vector<ProofReq*> here;
+        std::vector<uint64_t> offsets;
+        for (ProofReq& r : m_proofs) {
+            if (r.seen || slice.Number() != r.leaf / m_capacity + 1) continue;
+            r.seen = true;
+            r.offset = r.leaf % m_capacity;
+            if (r.offset >= slice.Count()) continue;   // past the end of the stream: reported by ProofLines()
+            r.slice_levels = height;
+            r.slice_number = slice.Number();
+            here.push_back(&r);
+            offsets.push_back(r.offset);
+        }
+        if (here.empty()) return vkmr_hip_reduce_async(d.dev, stream, slice.Cells(), slice.Count(), height, scratch, root_dev);
         void* sib = nullptr;
-        HipResult st = vkmr_hip_device_alloc(d.dev, (size_t)(height + 1) * sizeof(vkmr_digest), &sib);
+        HipResult st = vkmr_hip_device_alloc(d.dev, (here.size() * (size_t)height + 1) * sizeof(vkmr_digest), &sib);
+        if (st == VKMR_OK) m_proof_dev.push_back(std::make_pair(d.dev, sib));
         if (st == VKMR_OK && !m_proof_host) {
             void* h = nullptr;
-            st = vkmr_hip_host_alloc(130 * sizeof(vkmr_digest), &h);   // leaf + up to 64 levels in the slice + 64 above it
+            st = vkmr_hip_host_alloc(kMaxProofs * kProofRecord * sizeof(vkmr_digest), &h);   // per proof: leaf + up to 64 levels in the slice + 64 above it
             m_proof_host = static_cast<vkmr_digest*>(h);
         }
         if (st == VKMR_OK)
-            st = vkmr_hip_proof_async(d.dev, stream, slice.Cells(), slice.Count(), height, m_proof_offset, scratch, static_cast<vkmr_digest*>(sib), nullptr);
-        if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, m_proof_host, slice.Cells() + m_proof_offset, sizeof(vkmr_digest));
-        if (st == VKMR_OK && height) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, m_proof_host + 1, sib, (size_t)height * sizeof(vkmr_digest));
-        m_proof_dev = sib;
-        m_proof_dev_device = d.dev;
-        m_proof_dispatched = (st == VKMR_OK);
+            st = vkmr_hip_reduce_proofs_async(d.dev, stream, slice.Cells(), slice.Count(), height, scratch, root_dev, offsets.data(), (uint32_t)offsets.size(),
+                                              static_cast<vkmr_digest*>(sib));
+        for (size_t q = 0; q < here.size() && st == VKMR_OK; ++q) {
+            ProofReq& r = *here[q];
+            st = vkmr_hip_memcpy_d2h_async(d.dev, stream, m_proof_host + r.host_at, slice.Cells() + r.offset, sizeof(vkmr_digest));
+            if (st == VKMR_OK && height)
+                st = vkmr_hip_memcpy_d2h_async(d.dev, stream, m_proof_host + r.host_at + 1, static_cast<vkmr_digest*>(sib) + q * (size_t)height,
+                                               (size_t)height * sizeof(vkmr_digest));
+            r.dispatched = (st == VKMR_OK);
+        }
         return st;
     }
 
@@ -283,9 +304,7 @@ private:
         if (st == VKMR_OK) st = Acquire(di, &r.res);
         if (st != VKMR_OK) return st;
         st = vkmr_hip_event_record(d.dev, r.res.begin, stream);
-        if (st == VKMR_OK && m_proof_wanted && !m_proof_slice_seen && slice.Number() == m_proof_leaf / m_capacity + 1)
-            st = ProveInSlice(d, slice, height, r.res.scratch, stream);
-        if (st == VKMR_OK) st = vkmr_hip_reduce_async(d.dev, stream, slice.Cells(), slice.Count(), height, r.res.scratch, d.roots_dev + r.slot);
+        if (st == VKMR_OK) st = ReduceAndProve(d, slice, height, r.res.scratch, stream, d.roots_dev + r.slot);
         if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d.dev, stream, d.roots_host + r.slot, d.roots_dev + r.slot, sizeof(vkmr_digest));
         if (st == VKMR_OK) st = vkmr_hip_event_record(d.dev, r.res.done, stream);
         if (st != VKMR_OK) {
@@ -328,15 +347,20 @@ private:
         }
     }
 
-    // Everything of the proof has reached the host (the streams were synchronised): assemble the path.
+    // Everything of the proofs has reached the host (the streams were synchronised): assemble the paths.  upper: per
+    // dispatched proof (in request order) `upper_levels` siblings above the slices.
     void FinishProof(const vkmr_digest* upper, uint32_t upper_levels)
     {
-        if (!m_proof_dispatched || !m_proof_host || m_failed) return;
-        m_proof_leaf_digest = m_proof_host[0];
-        m_proof_path.assign(m_proof_host + 1, m_proof_host + 1 + m_proof_slice_levels);
-        for (uint32_t l = 0; l < upper_levels; ++l) m_proof_path.push_back(upper[l]);
-        m_proof_slice_pos = m_proof_slice_number - 1;
-        m_proof_done = true;
+        if (!m_proof_host || m_failed) return;
+        size_t nth = 0;
+        for (ProofReq& r : m_proofs) {
+            if (!r.dispatched) continue;
+            r.leaf_digest = m_proof_host[r.host_at];
+            r.path.assign(m_proof_host + r.host_at + 1, m_proof_host + r.host_at + 1 + r.slice_levels);
+            for (uint32_t l = 0; l < upper_levels; ++l) r.path.push_back(upper[nth * upper_levels + l]);
+            r.done = true;
+            ++nth;
+        }
     }
 
     // Root over all slice roots, in slice order, on the first device.
@@ -382,25 +406,38 @@ private:
         if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, vkmr_hip_reduce_scratch_bytes(total), &scratch);
         if (st == VKMR_OK) st = vkmr_hip_device_alloc(d0.dev, sizeof(vkmr_digest), &final_dev);
         if (st == VKMR_OK) st = vkmr_hip_host_alloc(sizeof(vkmr_digest), &final_host);
-        // the proof's upper part: the path of the leaf's slice among the slice roots (same tree as the combine)
+        // the proofs' upper parts: the paths of the leaves' slices among the slice roots -- written by the combine itself
+        // (same tree, same launches)
         void* up_sib = nullptr;
         uint32_t up_levels = 0;
-        if (st == VKMR_OK && m_proof_dispatched) {
+        std::vector<uint64_t> positions;
+        for (const ProofReq& r : m_proofs)
+            if (r.dispatched) positions.push_back((uint64_t)r.slice_number - 1);
+        vkmr_digest* upper_host = nullptr;
+        if (st == VKMR_OK && !positions.empty()) {
             up_levels = 1;
             while (((uint64_t)total + ((1ull << up_levels) - 1ull)) >> up_levels > 1) ++up_levels;
-            st = vkmr_hip_device_alloc(d0.dev, (size_t)up_levels * sizeof(vkmr_digest), &up_sib);
+            st = vkmr_hip_device_alloc(d0.dev, positions.size() * (size_t)up_levels * sizeof(vkmr_digest), &up_sib);
             if (st == VKMR_OK)
-                st = vkmr_hip_proof_async(d0.dev, d0.stream, roots, total, up_levels, m_proof_slice_number - 1, scratch, static_cast<vkmr_digest*>(up_sib), nullptr);
+                st = vkmr_hip_reduce_proofs_async(d0.dev, d0.stream, roots, total, up_levels, scratch, static_cast<vkmr_digest*>(final_dev), positions.data(),
+                                                  (uint32_t)positions.size(), static_cast<vkmr_digest*>(up_sib));
+            if (st == VKMR_OK) {
+                void* h = nullptr;
+                st = vkmr_hip_host_alloc(positions.size() * (size_t)up_levels * sizeof(vkmr_digest), &h);
+                upper_host = static_cast<vkmr_digest*>(h);
+            }
             if (st == VKMR_OK)
-                st = vkmr_hip_memcpy_d2h_async(d0.dev, d0.stream, m_proof_host + 1 + m_proof_slice_levels, up_sib, (size_t)up_levels * sizeof(vkmr_digest));
+                st = vkmr_hip_memcpy_d2h_async(d0.dev, d0.stream, upper_host, up_sib, positions.size() * (size_t)up_levels * sizeof(vkmr_digest));
+        } else if (st == VKMR_OK) {
+            st = vkmr_hip_combine_async(d0.dev, d0.stream, roots, total, scratch, static_cast<vkmr_digest*>(final_dev));
         }
-        if (st == VKMR_OK) st = vkmr_hip_combine_async(d0.dev, d0.stream, roots, total, scratch, static_cast<vkmr_digest*>(final_dev));
         if (st == VKMR_OK) st = vkmr_hip_memcpy_d2h_async(d0.dev, d0.stream, final_host, final_dev, sizeof(vkmr_digest));
         if (st == VKMR_OK) st = vkmr_hip_stream_sync(d0.dev, d0.stream);
         for (size_t i = 1; i < ndev && st == VKMR_OK; ++i)   // the other ranks' side of the gather
             if (m_devs[i].stream && gathered[i]) st = vkmr_hip_stream_sync(m_devs[i].dev, m_devs[i].stream);
         if (st == VKMR_OK) std::memcpy(top, final_host, sizeof(vkmr_digest));
-        if (st == VKMR_OK) FinishProof(m_proof_host ? m_proof_host + 1 + m_proof_slice_levels : nullptr, up_levels);
+        if (st == VKMR_OK) FinishProof(upper_host, up_levels);
+        vkmr_hip_host_free(upper_host);
         vkmr_hip_device_free(d0.dev, up_sib);
         for (size_t i = 0; i < ndev; ++i) vkmr_hip_device_free(m_devs[i].dev, gathered[i]);
         vkmr_hip_device_free(d0.dev, ordered);
@@ -423,15 +460,20 @@ private:
     std::vector<Reduction> m_inflight;
     std::vector<size_t> m_own_streams;
     vkmr_comm m_comm = nullptr;
-    // the requested Merkle proof (at most one per run)
-    bool m_proof_wanted = false, m_proof_slice_seen = false, m_proof_dispatched = false, m_proof_done = false;
-    uint64_t m_proof_leaf = 0, m_proof_offset = 0, m_proof_slice_pos = 0;
-    uint32_t m_proof_slice_levels = 0, m_proof_slice_number = 0;
-    vkmr_digest* m_proof_host = nullptr;   // pinned: leaf digest, siblings inside the slice, siblings above it
-    void* m_proof_dev = nullptr;
-    int m_proof_dev_device = -1;
-    vkmr_digest m_proof_leaf_digest{};
-    std::vector<vkmr_digest> m_proof_path;
+    // the requested Merkle proofs
+    static constexpr size_t kMaxProofs = 16;      // what one reduction writes in its pass (vkmr_hip_reduce_proofs_async)
+    static constexpr size_t kProofRecord = 66;    // pinned digests per proof: the leaf + up to 64 levels inside its slice (+ 1 spare)
+    struct ProofReq {
+        uint64_t leaf = 0, offset = 0;            // stream index; index inside its slice
+        uint32_t slice_number = 0, slice_levels = 0;
+        bool seen = false, dispatched = false, done = false;
+        size_t host_at = 0;                       // this proof's record in m_proof_host
+        vkmr_digest leaf_digest{};
+        std::vector<vkmr_digest> path;
+    };
+    std::vector<ProofReq> m_proofs;
+    vkmr_digest* m_proof_host = nullptr;          // pinned: per proof the leaf digest and the siblings inside its slice
+    std::vector<std::pair<int, void*>> m_proof_dev;   // device sibling arrays (device, pointer), freed with the object
 };
 
 }  // namespace

@@ -101,6 +101,12 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
                                meta_dev, count, out, tile, ntiles, (uint32_t)stagger);
             break;
         }
+        case 24:   // per-lane loads, two blocks (128 bytes) per trip (map_kernel MODE 5)
+            if (tile >= 1024u)
+                hipLaunchKernelGGL((map_kernel<512, 2048, 64, 5, true>), dim3(grid), dim3(512), (size_t)dyn_lds, s, data_dev, data_words, meta_dev, count, out, tile);
+            else
+                hipLaunchKernelGGL((map_kernel<256, 2048, 64, 5, true>), dim3(grid), dim3(256), (size_t)dyn_lds, s, data_dev, data_words, meta_dev, count, out, tile);
+            break;
         case 20: vkmr_map_presorted<256, 1024, 4, 1>(s, data_dev, data_words, meta_dev, count, out, 1024u); break;   // sort kernel + barrier-free hashing, tiles of 1024
         case 21: vkmr_map_presorted<256, 2048, 4, 1>(s, data_dev, data_words, meta_dev, count, out, 2048u); break;   // the same, tiles of 2048 (fewer mixed groups)
         case 22: vkmr_map_presorted<256, 1024, 4, 4>(s, data_dev, data_words, meta_dev, count, out, 1024u); break;   // four consecutive groups per ticket

@@ -38,6 +38,8 @@ using vkmr_dev::Node;
 //           times and re-fetched once it has left L2 (1.6x the algorithmic bytes at L2/fabric).
 //   MODE 1  per-wavefront gather: 16 lanes read one string's 64 contiguous bytes, four
 //           strings per load, transposed through LDS rows.  Kept as the measured alternative.
+//   MODE 5  (experiments build) MODE 2 with TWO blocks per trip: eight 16-byte loads (128 bytes) per lane, then two compressions -- a
+//           128-byte line is asked for by at most two trips instead of three (75 VGPRs: 6 wavefronts per SIMD).
 //   MODE 4  (experiments build) whole 128-byte lines through a two-line LDS window per lane: 1.06x the algorithmic HBM
 //           reads for long strings, but 272 bytes of LDS per lane = two wavefronts per SIMD, which the instruction
 //           pairing of the issue pass (isa_prio_pass.py) punishes: 2.56 vs 2.26 ms on rndm * 4096.
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 1) void map_kernel(c
                                                       Node* __restrict__ out, uint32_t tile)
 {
     constexpr int VKMR_MAP_THREADS = THREADS, VKMR_MAP_MAX_TILE = MAX_TILE, VKMR_MAP_STAGE_WORDS = STAGE_WORDS;
-    constexpr bool GATHER = (MODE == 1);   // MODE 0: stage tiles in LDS; 1: per-wavefront gather; 2: per-lane 16-byte loads
+    constexpr bool GATHER = (MODE == 1);   // MODE 0: stage tiles in LDS; 1: per-wavefront gather; 2: per-lane 16-byte loads; 5: per-lane, two blocks per trip
     constexpr bool LINEWIN = (MODE == 4);  // per-lane line-aligned loads through a two-line LDS window
     static_assert(!GATHER || STAGE_WORDS >= (THREADS / 64) * 64 * VKMR_MAP_GATHER_STRIDE, "staging area must hold the gather rows");
     static_assert(!LINEWIN || STAGE_WORDS >= THREADS * VKMR_MAP_WIN_STRIDE, "staging area must hold one window row per lane");
@@ -285,6 +287,81 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 1) void map_kernel(c
             load_line(data, data_words, line0 + 32, has && (unsigned long long)(line0 + 32) < wend, R8);
         }
 
+        // One block's words w (raw, as they lie in memory) of block b into the hash state: byte swap, padding, bit length, compression.
+        auto absorb = [&](uint32_t (&w)[16], uint32_t b) {
+            // valid bytes of the string inside this block: 0..64
+            const uint64_t boff = (uint64_t)b << 6;
+            const uint32_t r = (boff >= size) ? 0u : ((size - boff >= 64u) ? 64u : (uint32_t)(size - boff));
+            if (FULLFAST && __all(r == 64u || b >= nb)) {
+                // every string of the group still has 64 bytes here: plain byte swap
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(w[i]);
+            } else {
+                // Padding by arithmetic masks.  A gfx950 SIMD issues one "complex" VALU instruction per 4-cycle turn (v_perm_b32,
+                // v_cmp_*, v_cndmask_b32_e64, v_and_or_b32 ...) plus one "simple" one (add/sub, shifts right, and/or/xor,
+                // v_bitop3_b32) beside it, and SHA-256 already fills the complex slot (isa_prio_pass.py): so the select-by-compare
+                // form (two compares, two conditional moves and an and-or per word: 6 complex instructions) is spelled with
+                // simple ones -- only the byte swap stays complex.
+                //   M_i = all ones iff word i lies wholly inside the string; the word after the last such one takes the
+                //   terminator (when it falls into this block), the words after it are zero.
+                uint32_t term = ((boff <= size) && (size - boff < 64u)) ? 0xFFFFFFFFu : 0u;   // the 0x80 byte falls in this block
+                asm("" : "+v"(term));   // opaque: keeps `x & term` a v_and_b32 (LLVM would make each a v_cndmask_b32_e64, a complex instruction)
+                const uint32_t kb = (r & 3u) << 3;
+                const uint32_t keep = ~(0xFFFFFFFFu >> kb);                       // the kb / 8 leading bytes of the boundary word
+                const uint32_t padbit = 0x80000000u >> kb;
+                const uint32_t full = r >> 2;                                   // whole data words
+                uint32_t M[16];
+                whole_word_masks(full, M);                                      // M[i] = (i < full) ? ~0 : 0
+                uint32_t prev = term;                                           // "word i - 1 was a whole data word", and-ed with term
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t v = __builtin_bswap32(w[i]);
+                    const uint32_t bnd = __builtin_amdgcn_bitop3_b32(v, keep, padbit, 0xEA);      // (v & keep) | padbit
+                    const uint32_t u = bnd & prev;
+                    w[i] = __builtin_amdgcn_bitop3_b32(v, M[i], u, 0xE2);                         // M ? v : u
+                    prev = M[i] & term;
+                }
+            }
+            if (b + 1u == nb) {   // last block carries the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
+                w[14] = size >> 29;
+                w[15] = size << 3;
+            }
+#ifdef VKMR_EXPERIMENTS
+            if (SCHED != 0) {
+                if (b < nb) vkmr_dev::lds_compress<SCHED == 2, THREADS>(H, w, s_K, my_W);
+            } else
+#endif
+            if (b < nb) vkmr_dev::compress(H, w);
+        
+        };
+        if (MODE == 5 && !staged) {
+            // two blocks per trip: eight 16-byte loads, then two compressions
+            for (uint32_t b = 0; __any(b < nb); b += 2u) {
+                uint32_t w0[16], w1[16];
+                const uint64_t gbase = (uint64_t)start + ((uint64_t)b << 4);
+                if (gbase + 32u <= data_words) {
+                    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4_u* src = reinterpret_cast<const u32x4_u*>(data + gbase);
+                    u32x4_u v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = src[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w0[4 * q] = v[q].x; w0[4 * q + 1] = v[q].y; w0[4 * q + 2] = v[q].z; w0[4 * q + 3] = v[q].w;
+                        w1[4 * q] = v[4 + q].x; w1[4 * q + 1] = v[4 + q].y; w1[4 * q + 2] = v[4 + q].z; w1[4 * q + 3] = v[4 + q].w;
+                    }
+                } else {   // the buffer's end: word by word
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint64_t i0 = gbase + i, i1 = gbase + 16u + i;
+                        w0[i] = (i0 < data_words) ? data[i0] : 0u;
+                        w1[i] = (i1 < data_words) ? data[i1] : 0u;
+                    }
+                }
+                absorb(w0, b);
+                if (__any(b + 1u < nb)) absorb(w1, b + 1u);
+            }
+        } else
         for (uint32_t b = 0; __any(b < nb); ++b) {
             uint32_t w[16];
             // raw words of this block (garbage beyond the string is masked below)
@@ -343,49 +420,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 1) void map_kernel(c
                     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
                 }
             }
-            // valid bytes of the string inside this block: 0..64
-            const uint64_t boff = (uint64_t)b << 6;
-            const uint32_t r = (boff >= size) ? 0u : ((size - boff >= 64u) ? 64u : (uint32_t)(size - boff));
-            if (FULLFAST && __all(r == 64u || b >= nb)) {
-                // every string of the group still has 64 bytes here: plain byte swap
-#pragma unroll
-                for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(w[i]);
-            } else {
-                // Padding by arithmetic masks.  A gfx950 SIMD issues one "complex" VALU instruction per 4-cycle turn (v_perm_b32,
-                // v_cmp_*, v_cndmask_b32_e64, v_and_or_b32 ...) plus one "simple" one (add/sub, shifts right, and/or/xor,
-                // v_bitop3_b32) beside it, and SHA-256 already fills the complex slot (isa_prio_pass.py): so the select-by-compare
-                // form (two compares, two conditional moves and an and-or per word: 6 complex instructions) is spelled with
-                // simple ones -- only the byte swap stays complex.
-                //   M_i = all ones iff word i lies wholly inside the string; the word after the last such one takes the
-                //   terminator (when it falls into this block), the words after it are zero.
-                uint32_t term = ((boff <= size) && (size - boff < 64u)) ? 0xFFFFFFFFu : 0u;   // the 0x80 byte falls in this block
-                asm("" : "+v"(term));   // opaque: keeps `x & term` a v_and_b32 (LLVM would make each a v_cndmask_b32_e64, a complex instruction)
-                const uint32_t kb = (r & 3u) << 3;
-                const uint32_t keep = ~(0xFFFFFFFFu >> kb);                       // the kb / 8 leading bytes of the boundary word
-                const uint32_t padbit = 0x80000000u >> kb;
-                const uint32_t full = r >> 2;                                   // whole data words
-                uint32_t M[16];
-                whole_word_masks(full, M);                                      // M[i] = (i < full) ? ~0 : 0
-                uint32_t prev = term;                                           // "word i - 1 was a whole data word", and-ed with term
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t v = __builtin_bswap32(w[i]);
-                    const uint32_t bnd = __builtin_amdgcn_bitop3_b32(v, keep, padbit, 0xEA);      // (v & keep) | padbit
-                    const uint32_t u = bnd & prev;
-                    w[i] = __builtin_amdgcn_bitop3_b32(v, M[i], u, 0xE2);                         // M ? v : u
-                    prev = M[i] & term;
-                }
-            }
-            if (b + 1u == nb) {   // last block carries the 64-bit bit length (CPU path, SHA-256plus.cpp:100-117)
-                w[14] = size >> 29;
-                w[15] = size << 3;
-            }
-#ifdef VKMR_EXPERIMENTS
-            if (SCHED != 0) {
-                if (b < nb) vkmr_dev::lds_compress<SCHED == 2, THREADS>(H, w, s_K, my_W);
-            } else
-#endif
-            if (b < nb) vkmr_dev::compress(H, w);
+            absorb(w, b);
         }
         if (has) {
             uint32_t o[8];

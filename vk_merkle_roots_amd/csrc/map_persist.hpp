@@ -77,15 +77,21 @@ __device__ __forceinline__ void hash_group(const uint32_t* __restrict__ data, ui
                 unseen_wait(x0, x1, x2, x3);
                 w[0] = x0.x; w[1] = x0.y; w[2] = x0.z; w[3] = x0.w; w[4] = x1.x; w[5] = x1.y; w[6] = x1.z; w[7] = x1.w;
                 w[8] = x2.x; w[9] = x2.y; w[10] = x2.z; w[11] = x2.w; w[12] = x3.x; w[13] = x3.y; w[14] = x3.z; w[15] = x3.w;
-            } else {   // the buffer's end: word by word
+            } else if (data_words != 0) {   // the buffer's end: word by word
+                // Every load is issued by every lane, from an index clamped into the buffer: words beyond the buffer lie beyond the
+                // string (sizes are cut at the buffer's end) and are masked below like any byte beyond `size`.  No load sits under a
+                // condition of its own -- a value merged from "loaded" and "not loaded" lanes would be copied before the wait.
+                const uint64_t last = data_words - 1u;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const uint64_t idx = gbase + i;
-                    w[i] = 0u;
-                    if (idx < data_words) unseen_load_b32(w[i], data + idx);
+                    unseen_load_b32(w[i], data + (idx < last ? idx : last));
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
                                                     "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = 0u;
             }
         }
         const uint64_t boff = (uint64_t)b << 6;
@@ -329,6 +335,9 @@ __global__ __launch_bounds__(THREADS, 4) void map_persist_kernel(const uint32_t*
 
     if (threadIdx.x < VKMR_MAP_BINS) s_hist[threadIdx.x] = 0u;
     if (threadIdx.x == 0) { s_lo = ~0ull; s_hi = 0ull; s_outside = 0u; }
+    // Which tiles: b, b + G, b + 2G ...  (Tried: every tile after the first three taken by ticket, one atomic per tile -- the launch
+    // then ends when the work does instead of waiting for its slowest workgroup, 5.28 ms instead of 5.85, which is map_kernel's
+    // 5.2 ms and no better: profiles/r04_map_persist.txt.)
     // the extent the NEXT tile's end entries promise, known one tile ahead (uniform; carried around the loop as plain numbers)
     unsigned long long next_a0 = 0, next_hi = 0;
     bool next_ok = false;

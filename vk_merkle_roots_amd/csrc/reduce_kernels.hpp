@@ -33,8 +33,69 @@ struct SliceGeom { uint64_t n_full, n_last, in_stride, out_stride; uint32_t nsli
 
 __device__ __forceinline__ uint64_t slice_count(const SliceGeom& g) { return (blockIdx.y + 1u == g.nslices) ? g.n_last : g.n_full; }
 
-__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const Node* __restrict__ in0, SliceGeom geom,
-                                                                           Node* __restrict__ out0, uint32_t m)
+// Merkle proofs written DURING the reduction (the reference's to-do: "for an indicated leaf, allocate a buffer to hold and write
+// out the intermediate values during reduction", README.md:118-120).  For each of `k` leaves the lane that hashes the pair the
+// leaf's path node belongs to at tree level L stores the OTHER node of that pair (the node itself where it has no right
+// sibling: the duplicate-last rule) to sib[q * height + L].  No extra hash; per hash step a wavefront makes k scalar range
+// tests ("is path node q's pair one of the 64 this wavefront is forming?"), and the kernels are instantiated without all of it
+// for reductions that want no proof.  `level0`: tree level of the launch's input nodes.
+#define VKMR_MAX_PROOFS 16
+struct ProofArgs { uint32_t k, height; uint64_t index[VKMR_MAX_PROOFS]; Node* sib; };
+
+// The wavefront has just formed pairs of level-L nodes: lane i holds pair j_first + i * j_step as (l, r), when `valid`.
+template <bool PROOFS>
+__device__ __forceinline__ void note_siblings(const ProofArgs& pa, uint32_t L, uint64_t j_first, uint32_t j_step_log2, uint32_t lane, bool valid,
+                                              const uint32_t (&l)[8], const uint32_t (&r)[8])
+{
+    if (!PROOFS) return;
+    if (L >= pa.height) return;
+    for (uint32_t q = 0; q < pa.k; ++q) {
+        const uint64_t p = pa.index[q] >> L;                       // the path node at this level
+        const uint64_t d = (p >> 1) - j_first;                     // its pair, counted from lane 0's (wraps to huge when below)
+        if ((d >> j_step_log2) < 64u && (d & ((1ull << j_step_log2) - 1ull)) == 0ull) {   // wave-uniform
+            if (lane == (uint32_t)(d >> j_step_log2) && valid) {
+                Node t;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t.w[i] = (p & 1ull) ? l[i] : r[i];
+                pa.sib[(size_t)q * pa.height + L] = t;
+            }
+        }
+    }
+}
+
+// Does any proof's path run through the `span` level-`level0` nodes that begin at node `first`?  Asked ONCE per wavefront, so that
+// the thousands of wavefronts no path touches skip every test below (k scalar loads per hash step otherwise: +2.4 % on a slice
+// of 2^26 with 8 proofs, profiles/r04_proofs_in_the_pass.txt).
+template <bool PROOFS>
+__device__ __forceinline__ bool any_path_through(const ProofArgs& pa, uint32_t level0, uint64_t first, uint64_t span)
+{
+    if (!PROOFS) return false;
+    bool mine = false;
+    for (uint32_t q = 0; q < pa.k; ++q) mine = mine || ((pa.index[q] >> level0) - first) < span;
+    return mine && blockIdx.y == 0;
+}
+
+// The same for the shuffle steps of the collapse / tail kernels, where the hashing lanes are 2, 4, 8 ... apart: every hashing lane
+// tests its own pair (me, me + 1) of level-L nodes, x and r.
+template <bool PROOFS>
+__device__ __forceinline__ void note_sibling_of_lane(const ProofArgs& pa, uint32_t L, uint64_t me, bool hashing, const uint32_t (&x)[8], const uint32_t (&r)[8])
+{
+    if (!PROOFS) return;
+    if (L >= pa.height) return;
+    for (uint32_t q = 0; q < pa.k; ++q) {
+        const uint64_t p = pa.index[q] >> L;
+        if (hashing && (p >> 1) == (me >> 1)) {
+            Node t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t.w[i] = (p & 1ull) ? x[i] : r[i];
+            pa.sib[(size_t)q * pa.height + L] = t;
+        }
+    }
+}
+
+template <bool PROOFS>
+__device__ __forceinline__ void reduce_pass_body(const Node* __restrict__ in0, const SliceGeom& geom, Node* __restrict__ out0, uint32_t m,
+                                                 const ProofArgs& pa, uint32_t level0)
 {
     const uint64_t n_in = slice_count(geom);
     const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
@@ -46,6 +107,7 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
     const uint64_t base0 = gwave * (128ull << m);
     if (base0 >= n_in) return;   // wave-uniform; no workgroup barrier is used below
     Node* pend = reinterpret_cast<Node*>(pend_store) + wave * (VKMR_PASS_MAXM * 64);
+    const bool mine = any_path_through<PROOFS>(pa, level0, base0, 128ull << m);
     VKMR_STAMP(t_begin);
     VKMR_STAMP_RT(rt_begin);
 
@@ -96,6 +158,7 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
                         for (int i = 0; i < 8; ++i) r[i] = l[i];
                     }
                 }
+                if (PROOFS && mine) note_siblings<PROOFS>(pa, level0 + k, (first >> (k + 1)), 0u, lane, 2 * j < ck, l, r);
                 if (2 * j < ck) vkmr_dev::hash_pair(l, r, X);
             }
             ++k;
@@ -126,6 +189,20 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
 #endif
 }
 
+__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const Node* __restrict__ in0, SliceGeom geom,
+                                                                           Node* __restrict__ out0, uint32_t m)
+{
+    ProofArgs none;
+    none.k = 0u;
+    reduce_pass_body<false>(in0, geom, out0, m, none, 0u);
+}
+
+__global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_proofs_kernel(const Node* __restrict__ in0, SliceGeom geom,
+                                                                                  Node* __restrict__ out0, uint32_t m, ProofArgs pa, uint32_t level0)
+{
+    reduce_pass_body<true>(in0, geom, out0, m, pa, level0);
+}
+
 // Top of the tree: the last <= 128 nodes, exactly `levels` levels, ONE wavefront.  Level 1 comes from a coalesced pair
 // load; the next six levels stay inside the wavefront with __shfl_down, exactly the shape of the reference's
 // subgroupShuffleDown loop (src/shaders/SHA-256.comp:346-377).  Any levels left once a single node remains hash that
@@ -133,8 +210,9 @@ __global__ __launch_bounds__(VKMR_PASS_WAVES * 64) void reduce_pass_kernel(const
 // (Round 3 tried a 16-wavefront form for up to 2048 nodes, to save a launch: its wavefronts share one CU's four SIMDs
 // and each level costs 13.7 us against 9.4 us when reduce_collapse_kernel spreads them over the chip --
 // profiles/r03_reduce_top_kernels.txt -- so the schedule collapses down to 128 nodes again and this stays one wavefront.)
+template <bool PROOFS>
 __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0, uint32_t lane, uint64_t n_in,
-                                                 uint32_t& done, uint32_t levels, uint32_t steps)
+                                                 uint32_t& done, uint32_t levels, uint32_t steps, const ProofArgs& pa, uint32_t level0, bool mine)
 {
     for (uint32_t t = 0; t < steps && done < levels; ++t) {
         const uint64_t cnt = level_count(n_in, done);   // nodes alive at the current level
@@ -146,6 +224,7 @@ __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0
 #pragma unroll
             for (int i = 0; i < 8; ++i) r[i] = X[i];
         }
+        if (PROOFS && mine) note_sibling_of_lane<PROOFS>(pa, level0 + done, me, (lane & ((2u << t) - 1u)) == 0u && me < cnt, X, r);
         if ((lane & ((2u << t) - 1u)) == 0u && me < cnt) {
             uint32_t o[8];
             vkmr_dev::hash_pair(X, r, o);
@@ -156,8 +235,9 @@ __device__ __forceinline__ void shuffle_collapse(uint32_t (&X)[8], uint64_t idx0
     }
 }
 
-__global__ __launch_bounds__(64) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
-                                                         Node* __restrict__ root0)
+template <bool PROOFS>
+__device__ __forceinline__ void reduce_tail_body(const Node* __restrict__ in0, const SliceGeom& geom, uint32_t levels, Node* __restrict__ root0,
+                                                 const ProofArgs& pa, uint32_t level0)
 {
     const uint32_t n_in = (uint32_t)slice_count(geom);
     const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
@@ -171,11 +251,13 @@ __global__ __launch_bounds__(64) void reduce_tail_kernel(const Node* __restrict_
     if (2 * lane < n_in) {
         const Node a = vkmr_dev::load_node(in + 2 * lane);
         const Node b = vkmr_dev::load_node(in + ((2 * lane + 1 < n_in) ? 2 * lane + 1 : 2 * lane));
+        if (PROOFS && blockIdx.y == 0) note_siblings<PROOFS>(pa, level0, 0ull, 0u, lane, true, a.w, b.w);
         vkmr_dev::hash_pair(a.w, b.w, X);
     }
     uint32_t done = 1;
-    shuffle_collapse(X, lane, lane, n_in, done, levels, 6);
+    shuffle_collapse<PROOFS>(X, lane, lane, n_in, done, levels, 6, pa, level0, PROOFS && blockIdx.y == 0);
     while (done < levels) {   // a single node left: pair it with itself (wave-uniform loop)
+        note_sibling_of_lane<PROOFS>(pa, level0 + done, 0ull, lane == 0 && blockIdx.y == 0, X, X);
         uint32_t o[8];
         vkmr_dev::hash_pair(X, X, o);
 #pragma unroll
@@ -185,31 +267,63 @@ __global__ __launch_bounds__(64) void reduce_tail_kernel(const Node* __restrict_
     if (lane == 0) vkmr_dev::store_node(root, X);
 }
 
+__global__ __launch_bounds__(64) void reduce_tail_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                         Node* __restrict__ root0)
+{
+    ProofArgs none;
+    none.k = 0u;
+    reduce_tail_body<false>(in0, geom, levels, root0, none, 0u);
+}
+
+__global__ __launch_bounds__(64) void reduce_tail_proofs_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                                Node* __restrict__ root0, ProofArgs pa, uint32_t level0)
+{
+    reduce_tail_body<true>(in0, geom, levels, root0, pa, level0);
+}
+
 // Middle of the tree, where there are too few nodes to keep every SIMD busy: one
 // wavefront per workgroup (so the wavefronts spread over all CUs) collapses 128
 // nodes through `levels` (1..7) levels -- a coalesced pair load, then __shfl_down
 // steps as in the reference's subgroup shader.  Lane utilisation is poor by
 // construction here but these passes are latency-bound: what counts
 // is the ~9 us one wavefront needs per level, not the idle lanes.
-__global__ __launch_bounds__(VKMR_COLLAPSE_WAVES * 64) void reduce_collapse_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
-                                                                                     Node* __restrict__ out0)
+template <bool PROOFS>
+__device__ __forceinline__ void reduce_collapse_body(const Node* __restrict__ in0, const SliceGeom& geom, uint32_t levels, Node* __restrict__ out0,
+                                                     const ProofArgs& pa, uint32_t level0)
 {
     const uint64_t n_in = slice_count(geom);
     const Node* __restrict__ in = in0 + blockIdx.y * geom.in_stride;
     Node* __restrict__ out = out0 + blockIdx.y * geom.out_stride;
     const uint32_t lane = threadIdx.x & 63u;
     // each wavefront of the workgroup collapses its own 128 nodes
-    const uint64_t j = ((uint64_t)blockIdx.x * VKMR_COLLAPSE_WAVES + (threadIdx.x >> 6)) * 64u + lane;   // level-1 node of this lane
+    const uint64_t j0 = ((uint64_t)blockIdx.x * VKMR_COLLAPSE_WAVES + (threadIdx.x >> 6)) * 64u;
+    const uint64_t j = j0 + lane;   // level-1 node of this lane
+    const bool mine = any_path_through<PROOFS>(pa, level0, 2ull * j0, 128ull);
     uint32_t X[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (2 * j < n_in) {
         const Node a = vkmr_dev::load_node(in + 2 * j);
         const Node b = vkmr_dev::load_node(in + ((2 * j + 1 < n_in) ? 2 * j + 1 : 2 * j));
+        if (PROOFS && mine) note_siblings<PROOFS>(pa, level0, j0, 0u, lane, true, a.w, b.w);
         vkmr_dev::hash_pair(a.w, b.w, X);
     }
     uint32_t done = 1;
-    shuffle_collapse(X, j, lane, n_in, done, levels, 6);
+    shuffle_collapse<PROOFS>(X, j, lane, n_in, done, levels, 6, pa, level0, mine);
     const uint64_t jo = j >> (levels - 1u);
     if ((lane & ((1u << (levels - 1u)) - 1u)) == 0u && jo < level_count(n_in, levels)) vkmr_dev::store_node(out + jo, X);
+}
+
+__global__ __launch_bounds__(VKMR_COLLAPSE_WAVES * 64) void reduce_collapse_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                                                     Node* __restrict__ out0)
+{
+    ProofArgs none;
+    none.k = 0u;
+    reduce_collapse_body<false>(in0, geom, levels, out0, none, 0u);
+}
+
+__global__ __launch_bounds__(VKMR_COLLAPSE_WAVES * 64) void reduce_collapse_proofs_kernel(const Node* __restrict__ in0, SliceGeom geom, uint32_t levels,
+                                                                                            Node* __restrict__ out0, ProofArgs pa, uint32_t level0)
+{
+    reduce_collapse_body<true>(in0, geom, levels, out0, pa, level0);
 }
 
 // One level, one lane per pair (reference's BasicReduction shader, SHA-256.comp:393-434,

@@ -7,7 +7,6 @@
 //                       reduce_level_kernel    one level per launch, cross-check    (SHA-256.comp:393-434)
 //   sha256d_device.hpp  the SHA-256 round / compression building blocks
 //   meta_kernels.hpp    sizes_*_kernel         metadata entries from 16-bit sizes   (Batches.cpp:64-121)
-//   split_kernels.hpp   split_*_kernel         text -> packed batch on the device   (Inputs.cpp:75-101, Batches.cpp:64-121)
 //
 // Host side: plain launches on the caller's stream; no allocation, no sync inside
 // the *_async entry points.
@@ -26,7 +25,10 @@ using vkmr_dev::Node;
 
 #include "map_kernel.hpp"
 #include "meta_kernels.hpp"
-#include "split_kernels.hpp"
+#ifdef VKMR_EXPERIMENTS
+#include "../../include/vkmr_hip_experiments.h"
+#include "experiments/split_kernels.hpp"   // text -> packed batch on the device: measured, no gain, not shipped (include/vkmr_hip_experiments.h)
+#endif
 #include "reduce_kernels.hpp"
 #include "reduce_plan.hpp"
 
@@ -389,6 +391,7 @@ vkmr_status vkmr_hip_metadata_from_sizes_async(int dev, vkmr_stream s, const uin
     return VKMR_OK;
 }
 
+#ifdef VKMR_EXPERIMENTS
 // ---- text -> packed batch (split_kernels.hpp) ---------------------------------------------------------------------------
 namespace {
 struct SplitScratch { uint32_t *blk_count, *blk_after, *wblocks; vkmr_split::Line* lines; size_t bytes; };
@@ -437,6 +440,7 @@ vkmr_status vkmr_hip_split_text_async(int dev, vkmr_stream s, const uint8_t* tex
     VKMR_TRY(hipGetLastError());
     return VKMR_OK;
 }
+#endif   // VKMR_EXPERIMENTS
 
 // See the header: the first copy and the first launch of a process, taken out of the caller's pipeline.
 vkmr_status vkmr_hip_warm_up(int dev, vkmr_stream s, unsigned what, size_t copy_bytes)
@@ -518,20 +522,23 @@ size_t vkmr_hip_reduce_scratch_bytes(uint64_t count)
 // levels each; slice k's root goes to roots[k].  The step sequence is that of a full
 // slice; a shorter last slice rides along (its surplus wavefronts exit at once).
 static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32_t nslices, uint64_t n_full, uint64_t n_last,
-                                 uint32_t height, Node* scratch, Node* roots)
+                                 uint32_t height, Node* scratch, Node* roots, const ProofArgs* proofs = nullptr)
 {
     const Node* in = digests;
     uint64_t n = n_full, nl = n_last, in_stride = n_full;
     uint32_t left = height;
     Node* bufA = scratch;
     Node* bufB = nullptr;
+    const bool prove = proofs && proofs->k > 0;   // the kernels that also write the siblings of the proofs' path nodes (reduce_kernels.hpp)
     for (int pass = 0;; ++pass) {
         const ReduceStep st = next_step(n, left, nslices);
+        const uint32_t level0 = height - left;     // tree level of this launch's input nodes
         SliceGeom g;
         g.n_full = n; g.n_last = nl; g.in_stride = in_stride; g.nslices = nslices;
         if (st.kind == STEP_TAIL) {
             g.out_stride = 1;
-            hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(64), 0, stream, in, g, left, roots);
+            if (prove) hipLaunchKernelGGL(reduce_tail_proofs_kernel, dim3(1, nslices), dim3(64), 0, stream, in, g, left, roots, *proofs, level0);
+            else hipLaunchKernelGGL(reduce_tail_kernel, dim3(1, nslices), dim3(64), 0, stream, in, g, left, roots);
             VKMR_TRY(hipGetLastError());
             return VKMR_OK;
         }
@@ -548,11 +555,13 @@ static vkmr_status reduce_launch(hipStream_t stream, const Node* digests, uint32
             const uint64_t waves = ceil_shift(n, 7 + m);
             const uint64_t grid = (waves + VKMR_PASS_WAVES - 1) / VKMR_PASS_WAVES;
             if (grid > 0x7fffffffull) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_async: slice too large");
-            hipLaunchKernelGGL(reduce_pass_kernel, dim3((uint32_t)grid, nslices), dim3(VKMR_PASS_WAVES * 64), 0, stream, in, g, out, m);
+            if (prove) hipLaunchKernelGGL(reduce_pass_proofs_kernel, dim3((uint32_t)grid, nslices), dim3(VKMR_PASS_WAVES * 64), 0, stream, in, g, out, m, *proofs, level0);
+            else hipLaunchKernelGGL(reduce_pass_kernel, dim3((uint32_t)grid, nslices), dim3(VKMR_PASS_WAVES * 64), 0, stream, in, g, out, m);
         } else {
             const uint64_t cwaves = ceil_shift(n, 7);
-            hipLaunchKernelGGL(reduce_collapse_kernel, dim3((uint32_t)((cwaves + VKMR_COLLAPSE_WAVES - 1) / VKMR_COLLAPSE_WAVES), nslices),
-                               dim3(VKMR_COLLAPSE_WAVES * 64), 0, stream, in, g, st.levels, out);
+            const dim3 cgrid((uint32_t)((cwaves + VKMR_COLLAPSE_WAVES - 1) / VKMR_COLLAPSE_WAVES), nslices);
+            if (prove) hipLaunchKernelGGL(reduce_collapse_proofs_kernel, cgrid, dim3(VKMR_COLLAPSE_WAVES * 64), 0, stream, in, g, st.levels, out, *proofs, level0);
+            else hipLaunchKernelGGL(reduce_collapse_kernel, cgrid, dim3(VKMR_COLLAPSE_WAVES * 64), 0, stream, in, g, st.levels, out);
         }
         VKMR_TRY(hipGetLastError());
         in = out;
@@ -606,6 +615,35 @@ vkmr_status vkmr_hip_proof_async(int dev, vkmr_stream s, const vkmr_digest* dige
     if (root_dev)
         return reduce_launch(S(s), leaves, 1, count, count, height, reinterpret_cast<Node*>(scratch_dev), reinterpret_cast<Node*>(root_dev));
     return VKMR_OK;
+}
+
+// The reduction of vkmr_hip_reduce_async that ALSO writes the Merkle proofs of `k` leaves while it runs (the reference's to-do,
+// README.md:118-120): siblings_dev[q * height + l] = the sibling of leaf indices[q]'s path node at level l.  Same launches, same
+// root, no extra hash (reduce_kernels.hpp: note_siblings); vkmr_hip_proof_async stays as the independent cross-check.
+vkmr_status vkmr_hip_reduce_proofs_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint64_t count, uint32_t height, void* scratch_dev,
+                                         vkmr_digest* root_dev, const uint64_t* indices, uint32_t k, vkmr_digest* siblings_dev)
+{
+    if (k == 0) return vkmr_hip_reduce_async(dev, s, digests_dev, count, height, scratch_dev, root_dev);
+    if (!digests_dev || !root_dev || !indices || !siblings_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_proofs_async: null pointer");
+    if (k > VKMR_MAX_PROOFS) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_proofs_async: more than 16 proofs in one reduction");
+    if (!height_ok(count, height)) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_proofs_async: height does not reduce count to one node");
+    if (count > VKMR_TAIL_MAX && !scratch_dev) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_proofs_async: null scratch");
+    ProofArgs pa;
+    pa.k = k;
+    pa.height = height;
+    pa.sib = reinterpret_cast<Node*>(siblings_dev);
+    for (uint32_t q = 0; q < VKMR_MAX_PROOFS; ++q) pa.index[q] = 0;
+    for (uint32_t q = 0; q < k; ++q) {
+        if (indices[q] >= count) return fail(VKMR_ERR_INVALID, "vkmr_hip_reduce_proofs_async: index out of range");
+        pa.index[q] = indices[q];
+    }
+    VKMR_TRY(hipSetDevice(dev));
+    if (height == 0) {   // one node, no level: the root is the node (reduce_tail_kernel), no sibling exists
+        return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), 1, count, count, height, reinterpret_cast<Node*>(scratch_dev),
+                             reinterpret_cast<Node*>(root_dev));
+    }
+    return reduce_launch(S(s), reinterpret_cast<const Node*>(digests_dev), 1, count, count, height, reinterpret_cast<Node*>(scratch_dev),
+                         reinterpret_cast<Node*>(root_dev), &pa);
 }
 
 vkmr_status vkmr_hip_reduce_slices_async(int dev, vkmr_stream s, const vkmr_digest* digests_dev, uint32_t nslices,

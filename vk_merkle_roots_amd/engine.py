@@ -221,6 +221,22 @@ class HipDevice:
             b.free()
         return sib, root
 
+    def reduce_with_proofs(self, digests_buf, count, height, indices):
+        """(siblings [k, height, 8], root [8]): the reduction that writes the proofs of leaves `indices` while it runs
+        (vkmr_hip_reduce_proofs_async; k <= 16)."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        k = int(idx.shape[0])
+        d_sib = self.alloc(32 * max(height, 1) * max(k, 1))
+        d_root = self.alloc(32)
+        d_scratch = self.reduce_scratch(count)
+        check(self.lib.vkmr_hip_reduce_proofs_async(self.index, self.stream, digests_buf.ptr, count, height, d_scratch.ptr, d_root.ptr,
+                                                    idx.ctypes.data if k else None, k, d_sib.ptr), "vkmr_hip_reduce_proofs_async")
+        sib = self.download(d_sib, 32 * height * k).reshape(k, height, 8) if height and k else np.zeros((k, height, 8), np.uint32)
+        root = self.download(d_root, 32)
+        for b in (d_sib, d_root, d_scratch):
+            b.free()
+        return sib, root
+
     def reduce_scratch(self, count, levels_variant=False):
         fn = self.lib.vkmr_hip_reduce_levels_scratch_bytes if levels_variant else self.lib.vkmr_hip_reduce_scratch_bytes
         return self.alloc(fn(count))

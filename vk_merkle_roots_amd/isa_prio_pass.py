@@ -42,7 +42,9 @@ COMPLEX_ASSUMED = {"v_add_lshl_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_sub_c
 ASSUMED_PER_BLOCK = 16
 # Hash blocks every kernel must show (hash_blocks()): the node hash once per code path that hashes pairs, a 64-byte block and
 # the digest hash per map_kernel instantiation.  A listing with other counts is not the code the static counts were taken from.
-EXPECTED_HASH_BLOCKS = {"reduce_pass_kernel": 1, "reduce_level_kernel": 1, "reduce_collapse_kernel": 2, "reduce_tail_kernel": 2, "map_kernel": 2,
+EXPECTED_HASH_BLOCKS = {"ELi64ELi5ELb1": 3,   # experiments build: map_kernel MODE 5 (two blocks per trip: two block bodies + the digest); first match wins
+                        "reduce_pass_kernel": 1, "reduce_level_kernel": 1, "reduce_collapse_kernel": 2, "reduce_tail_kernel": 3, "map_kernel": 2,
+                        "reduce_pass_proofs_kernel": 1, "reduce_collapse_proofs_kernel": 2, "reduce_tail_proofs_kernel": 3,
                         "map_persist_kernel": 4, "map_hash_sorted_kernel": 2}   # the last two: experiments build (staged + per-lane loop; block + digest)
 
 _INSTR = re.compile(r"^\s+([a-z_0-9]+)\s*(.*)$")
@@ -241,7 +243,10 @@ def hash_blocks(lines):
             bb["complex" if k == "C" else "simple"] += 1
             if "v_alignbit_b32" in ln:
                 bb["rotates"] += 1
-        if ln.strip().startswith("s_endpgm"):
+        if ln.strip().startswith("s_endpgm"):      # ends a block, not the kernel: early exits come before the hashes in some layouts
+            close()
+            bb = {"valu": 0, "complex": 0, "simple": 0, "rotates": 0}
+        if ln.startswith(".Lfunc_end"):
             close()
             cur, bb = None, None
     return {k: v for k, v in out.items() if v}
@@ -299,9 +304,12 @@ def audit(lines):
             ops[b] = ops.get(b, 0) + 1
             if b == "v_alignbit_b32":
                 rot += 1
-        if ln.strip().startswith("s_endpgm"):
+        if ln.strip().startswith("s_endpgm"):      # ends a block, not the kernel (see hash_blocks)
+            close()
+        if ln.startswith(".Lfunc_end"):
             close()
             cur = None
+    close()
     errors = []
     for kernel, n in sorted(blocks.items()):
         want = next((v for k, v in EXPECTED_HASH_BLOCKS.items() if k in kernel), None)
