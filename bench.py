@@ -444,7 +444,7 @@ def static_counts():
     for k, v in hb.items():
         if "map_kernel" in k and len(v) >= 2:
             m = k.split("map_kernelILi")[1].split("EEv")[0].replace("ELi", ", ").replace("ELb", ", ")
-            out["map"][m] = {"block": v[0], "digest": v[1]}
+            out["map"][m] = {"block": v[0], "digest": v[-1]}     # the digest hash is the last hash block of a map kernel (the two-blocks-per-trip mode has two block bodies)
     return out
 
 

@@ -109,8 +109,8 @@ def test_docs_name_only_entry_points_that_exist():
 
 def test_the_product_library_carries_no_experiment_knobs(native):
     """the A/B knobs (VKMR_MAP_VARIANT / _FIT / _TILE / _DYNLDS) and the non-shipped map_kernel instantiations
-    live in the experiments build only; the product picks its fetch mode from the batch alone and ships three
-    instantiations (LDS-staged tiles, per-lane loads with 512 and with 256 lanes)."""
+    live in the experiments build only; the product picks its fetch mode from the batch alone and ships five
+    instantiations (LDS-staged tiles; per-lane loads, one block per trip and two, each with 512 and with 256 lanes)."""
     import subprocess
     from vk_merkle_roots_amd import build
     blob = open(build.HIP_LIB, "rb").read()
@@ -118,7 +118,7 @@ def test_the_product_library_carries_no_experiment_knobs(native):
         assert knob not in blob, knob
     syms = subprocess.run(["nm", "-C", build.HIP_LIB], stdout=subprocess.PIPE).stdout.decode()
     kernels = sorted({l.split(" V ")[1] for l in syms.splitlines() if " V void map_kernel<" in l})
-    assert len(kernels) == 3, kernels
+    assert len(kernels) == 5, kernels
     assert any("map_kernel<512, 1024, 17664, 0, false, 0>" in k for k in kernels)
     if os.path.exists(build.EXP_LIB):
         assert b"VKMR_MAP_VARIANT" in open(build.EXP_LIB, "rb").read()

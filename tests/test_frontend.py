@@ -325,9 +325,10 @@ def _fold_proof(lines):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{}, {"VKMR_SLICE_LOG2": "16"}, {"VKMR_SLICE_LOG2": "13", "VKMR_SLICE_BUDGET": "2"}, {"VKMR_SLICE_LOG2": "17", "_ndev": "4"}])
 def test_hip_merkle_proof_folds_to_the_root(native, golden, env):
-    """VKMR_PROOF_INDEX on the GPU (the reference's to-do, README.md:118-120): siblings inside the leaf's slice come from
-    vkmr_hip_proof_async on the reduction's stream, those above from a proof over the slice roots; folding them with
-    hashlib gives the root of the same run, which is the golden one."""
+    """VKMR_PROOF_INDEX on the GPU (the reference's to-do, README.md:118-120): the siblings inside a leaf's slice are written
+    by that slice's reduction as it runs (vkmr_hip_reduce_proofs_async), those above by the combine of the slice roots;
+    folding them with hashlib gives the root of the same run, which is the golden one.  One leaf per run, then all five --
+    and one that is not in the stream -- in ONE run."""
     s = golden["streams"]["G3_rndm_42_1048576_127"]
     stream = golden_stream(native, s)
     leaves = [l for l in stream.split(b"\n") if l]
@@ -342,6 +343,22 @@ def test_hip_merkle_proof_folds_to_the_root(native, golden, env):
         assert proof and proof[0].split()[2] == str(index)
         assert proof[0].split()[-1] == hashlib.sha256(hashlib.sha256(leaves[index]).digest()).digest().hex()
         assert _fold_proof(proof) == s["root"], (index, env)
+    wanted = [0, 65535, 65536, 700001, 1048575, 1048576, 65536]
+    r, out, m = run_vkmr(native, "hip:all" if ndev > 1 else "hip:0", stream, dict(env, VKMR_PROOF_INDEX=",".join(str(i) for i in wanted)))
+    assert m and m["root"] == s["root"], (env, r.stderr[-300:])
+    blocks = []
+    for l in (l for l in out if l.startswith("proof: ")):
+        if l.startswith("proof: leaf "):
+            blocks.append([l])
+        else:
+            blocks[-1].append(l)
+    assert [b[0].split()[2] for b in blocks] == [str(i) for i in wanted]
+    for index, b in zip(wanted, blocks):
+        if index >= len(leaves):
+            assert "is not in the stream" in b[0] and len(b) == 1
+            continue
+        assert b[0].split()[-1] == hashlib.sha256(hashlib.sha256(leaves[index]).digest()).digest().hex()
+        assert _fold_proof(b) == s["root"], (index, env)
 
 
 @pytest.mark.gpu

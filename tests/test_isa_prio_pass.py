@@ -208,4 +208,4 @@ def test_the_shipped_library_is_covered_by_the_issue_model(native):
     names = " ".join(rec["audit"]["blocks"])
     for kernel in ("reduce_pass_kernel", "reduce_collapse_kernel", "reduce_tail_kernel", "reduce_level_kernel", "map_kernel"):
         assert kernel in names
-    assert sum(1 for k in rec["audit"]["blocks"] if "map_kernel" in k) == 3    # the three shipped instantiations
+    assert sum(1 for k in rec["audit"]["blocks"] if "map_kernel" in k) == 5    # the five shipped instantiations: staged, per-lane x 2 launch widths, two-block x 2

@@ -33,7 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "map_kernel.hpp"
+#include "../map_kernel.hpp"
 
 typedef uint32_t vkmr_u32x4 __attribute__((ext_vector_type(4)));
 

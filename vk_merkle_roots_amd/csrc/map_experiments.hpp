@@ -9,7 +9,7 @@
 #pragma once
 extern "C++" {   // this header is included from inside the ABI's extern "C" block
 #include "experiments/map_presort.hpp"
-#include "map_persist.hpp"
+#include "experiments/map_persist.hpp"
 
 static int vkmr_exp_cus()
 {

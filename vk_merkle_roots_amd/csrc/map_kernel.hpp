@@ -38,8 +38,9 @@ using vkmr_dev::Node;
 //           times and re-fetched once it has left L2 (1.6x the algorithmic bytes at L2/fabric).
 //   MODE 1  per-wavefront gather: 16 lanes read one string's 64 contiguous bytes, four
 //           strings per load, transposed through LDS rows.  Kept as the measured alternative.
-//   MODE 5  (experiments build) MODE 2 with TWO blocks per trip: eight 16-byte loads (128 bytes) per lane, then two compressions -- a
-//           128-byte line is asked for by at most two trips instead of three (75 VGPRs: 6 wavefronts per SIMD).
+//   MODE 5  MODE 2 with TWO blocks per trip (shipped for strings of 512 B and more on average): eight 16-byte loads (128 bytes) per lane, then two compressions -- a
+//           128-byte line is asked for by at most two trips instead of three: 2.0x instead of 2.6x the algorithmic reads at the L2-fabric
+//           boundary on rndm * 4096 in the same time (87 VGPRs: 5 wavefronts per SIMD; profiles/r04_long_strings_two_blocks.txt).
 //   MODE 4  (experiments build) whole 128-byte lines through a two-line LDS window per lane: 1.06x the algorithmic HBM
 //           reads for long strings, but 272 bytes of LDS per lane = two wavefronts per SIMD, which the instruction
 //           pairing of the issue pass (isa_prio_pass.py) punishes: 2.56 vs 2.26 ms on rndm * 4096.

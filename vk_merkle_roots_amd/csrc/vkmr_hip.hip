@@ -278,13 +278,17 @@ vkmr_status vkmr_hip_event_elapsed_ms(int dev, vkmr_event begin, vkmr_event end,
 // ---- map ------------------------------------------------------------------------
 
 // What the last vkmr_hip_map_async of this process chose (reported by vkmr_hip_kernel_info).
-enum { MAP_NONE = 0, MAP_STAGED, MAP_DIRECT512, MAP_DIRECT256, MAP_EXPERIMENT };
+enum { MAP_NONE = 0, MAP_STAGED, MAP_DIRECT512, MAP_DIRECT256, MAP_LONG512, MAP_LONG256, MAP_EXPERIMENT };
 static std::atomic<int> g_last_map_mode{MAP_NONE};       // diagnostics only; several host threads may drive different devices
 static std::atomic<uint32_t> g_last_map_tile{0};
 
 // The shipped fetch modes (csrc/map_kernel.hpp).  The mode is chosen from the batch alone:
 //   average packed string < 128 B   LDS-staged tiles (HBM traffic == algorithmic bytes)
-//   longer                          per-lane 16-byte loads, 8 wavefronts per SIMD (256-lane workgroups when the launch is short)
+//   128 B .. 512 B                  per-lane 16-byte loads, one 64-byte block per trip, 8 wavefronts per SIMD (256-lane workgroups when the launch is short)
+//   512 B and more                  per-lane loads, TWO blocks (128 bytes) per trip: a 128-byte line is asked for by at most two trips instead
+//                                   of three -- 8.6 instead of 11.3 GB at the L2-fabric boundary for 4.3 GB of rndm * 4096, the same
+//                                   2.29 ms (87 VGPRs, 5 wavefronts per SIMD); at 150 B on average it is 3 % slower, hence the threshold
+//                                   (profiles/r04_long_strings_two_blocks.txt)
 // Round 2 also shipped a third mode for strings of 1 KiB and more -- whole 128-byte lines through a per-lane LDS window,
 // 1.06x instead of 1.46x the algorithmic reads for 1-2 % of time.  Its 272 bytes of LDS per lane allow two wavefronts
 // per SIMD, and since the issue pass (isa_prio_pass.py) the instruction pairing that decides the speed needs
@@ -294,6 +298,8 @@ static std::atomic<uint32_t> g_last_map_tile{0};
 #define VKMR_MAP_STAGED_KERNEL map_kernel<512, 1024, 17664, 0, false, 0>
 #define VKMR_MAP_DIRECT512_KERNEL map_kernel<512, 2048, 64, 2, true, 0>
 #define VKMR_MAP_DIRECT256_KERNEL map_kernel<256, 2048, 64, 2, true, 0>
+#define VKMR_MAP_LONG512_KERNEL map_kernel<512, 2048, 64, 5, true, 0>
+#define VKMR_MAP_LONG256_KERNEL map_kernel<256, 2048, 64, 5, true, 0>
 
 // Strings per LDS-staged tile: what is expected to fit the staging area, three standard deviations of a tile's
 // size below it (string lengths spread like rndm's, uniform in [1, max]: sigma / mean of T strings is about
@@ -349,7 +355,13 @@ vkmr_status vkmr_hip_map_async(int dev, vkmr_stream s, const uint32_t* data_dev,
     uint32_t tile = direct_tile(count);
     if (avg_words >= 32) {
         // strings of 128 B and more on average (a short launch: smaller workgroups spread it over the chip)
-        if (tile >= 1024u) {
+        if (avg_words >= 128 && tile >= 1024u) {
+            g_last_map_mode = MAP_LONG512;
+            hipLaunchKernelGGL((VKMR_MAP_LONG512_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        } else if (avg_words >= 128) {
+            g_last_map_mode = MAP_LONG256;
+            hipLaunchKernelGGL((VKMR_MAP_LONG256_KERNEL), dim3(tiles_of(count, tile)), dim3(256), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
+        } else if (tile >= 1024u) {
             g_last_map_mode = MAP_DIRECT512;
             hipLaunchKernelGGL((VKMR_MAP_DIRECT512_KERNEL), dim3(tiles_of(count, tile)), dim3(512), 0, S(s), data_dev, data_words, meta_dev, count, out, tile);
         } else {
@@ -481,6 +493,8 @@ const char* vkmr_hip_kernel_info(void)
         case MAP_STAGED: map = "map=" VKMR_STR((VKMR_MAP_STAGED_KERNEL)) " LDS-staged tiles sorted by block count"; break;
         case MAP_DIRECT512: map = "map=" VKMR_STR((VKMR_MAP_DIRECT512_KERNEL)) " per-lane 16-byte loads"; break;
         case MAP_DIRECT256: map = "map=" VKMR_STR((VKMR_MAP_DIRECT256_KERNEL)) " per-lane 16-byte loads, short launch"; break;
+        case MAP_LONG512: map = "map=" VKMR_STR((VKMR_MAP_LONG512_KERNEL)) " per-lane 16-byte loads, two blocks per trip"; break;
+        case MAP_LONG256: map = "map=" VKMR_STR((VKMR_MAP_LONG256_KERNEL)) " per-lane 16-byte loads, two blocks per trip, short launch"; break;
 #ifdef VKMR_EXPERIMENTS
         case MAP_EXPERIMENT: map = "map=EXPERIMENT (VKMR_MAP_VARIANT; not a product build)"; break;
 #endif

@@ -42,7 +42,7 @@ COMPLEX_ASSUMED = {"v_add_lshl_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_sub_c
 ASSUMED_PER_BLOCK = 16
 # Hash blocks every kernel must show (hash_blocks()): the node hash once per code path that hashes pairs, a 64-byte block and
 # the digest hash per map_kernel instantiation.  A listing with other counts is not the code the static counts were taken from.
-EXPECTED_HASH_BLOCKS = {"ELi64ELi5ELb1": 3,   # experiments build: map_kernel MODE 5 (two blocks per trip: two block bodies + the digest); first match wins
+EXPECTED_HASH_BLOCKS = {"ELi64ELi5ELb1": 3,   # map_kernel MODE 5 (two blocks per trip: two block bodies + the digest); first match wins
                         "reduce_pass_kernel": 1, "reduce_level_kernel": 1, "reduce_collapse_kernel": 2, "reduce_tail_kernel": 3, "map_kernel": 2,
                         "reduce_pass_proofs_kernel": 1, "reduce_collapse_proofs_kernel": 2, "reduce_tail_proofs_kernel": 3,
                         "map_persist_kernel": 4, "map_hash_sorted_kernel": 2}   # the last two: experiments build (staged + per-lane loop; block + digest)
