@@ -102,7 +102,7 @@ def test_docs_name_only_entry_points_that_exist():
     for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
         text = open(os.path.join(ROOT, doc)).read()
         for name in set(re.findall(r"\b(vkmr_hip_[a-z0-9_]+)\b", text)):
-            if name in ("vkmr_hip_h", "vkmr_hip_comm_", "vkmr_hip_combine"):   # file name fragment / prefix mention / round-1 name discussed in DESIGN
+            if name in ("vkmr_hip_h", "vkmr_hip_experiments", "vkmr_hip_comm_", "vkmr_hip_combine"):   # file name fragments / prefix mention / round-1 name discussed in DESIGN
                 continue
             assert name in declared or name + "_async" in declared or name.rstrip("_") in {d[: len(name.rstrip("_"))] for d in declared}, (doc, name)
 

@@ -135,3 +135,11 @@ def test_what_an_eight_gpu_line_says_about_its_gather_and_its_golden_roots():
     assert bench.check_against_golden(golden, 42, 8, golden["combined"]["4"], subs) == (False, True)
     assert bench.check_against_golden(golden, 42, 4, golden["combined"]["4"], subs[:4]) == (True, True)
     assert bench.check_against_golden(None, 42, 8, "", []) == (None, None)
+
+
+def test_the_golden_file_pins_config5():
+    """bench.py's config5_full leg checks its root against what the reference's own CPU path printed for `rndm 42 2^24 4096`
+    (BASELINE configs[4] at full size: 34 GB of text, 38 minutes of the reference; tests/golden/make_big_roots.py --config5)."""
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "big_roots.json")))["config5"]
+    assert rec["generator"] == "rndm 42 16777216 4096" and rec["items"] == 1 << 24 and len(rec["root"]) == 64
+    assert rec["bytes"] > 34e9
