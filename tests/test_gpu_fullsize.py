@@ -2,6 +2,8 @@
 threaded oracle and through size-independent properties (any slicing gives the same
 root; both reduction variants agree), and configs[4] in miniature-at-scale (2^18 x 4 KiB
 strings: the multi-block padding path)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -85,11 +87,13 @@ def test_config5_long_strings(gpu, oracle):
 def test_config5_full_2p24_x_4k(gpu, oracle):
     """BASELINE configs[4] at full size: rndm <seed> 2^24 4096 (about 34 GB of input, 1..65 blocks per
     string), streamed as 16 batches of 2^20 strings (a packed batch addresses at most 2^32 words) into 2
-    slices of 2^23 (the reference's slice); every leaf digest and the root against the threaded oracle."""
+    slices of 2^23 (the reference's slice); every leaf digest and the root against the threaded oracle -- and the root
+    against what the REFERENCE's CPU path printed for this very stream (tests/golden/big_roots.json, config5: rndm 42 2^24 4096,
+    38 minutes of the reference)."""
     import vk_merkle_roots_amd as vk
     from vk_merkle_roots_amd.engine import digest_hex
     n, per = 1 << 24, 1 << 20
-    stream = vk.RndmStream(5, 4096)
+    stream = vk.RndmStream(42, 4096)
     d_digests = gpu.alloc(32 * n)
     want = np.zeros((n, 8), dtype=np.uint32)
     total_bytes = 0
@@ -111,7 +115,11 @@ def test_config5_full_2p24_x_4k(gpu, oracle):
     d_roots, d_top, d_final = gpu.alloc(64), gpu.reduce_scratch(2), gpu.alloc(32)
     gpu.reduce_slices_async(d_digests, 2, 1 << 23, 1 << 23, 23, d_scratch, d_roots)
     gpu.reduce_async(d_roots, 2, 1, d_top, d_final)
-    assert digest_hex(gpu.download(d_final, 32)) == oracle.hex(oracle.root(want, threads=64))
+    root = digest_hex(gpu.download(d_final, 32))
+    assert root == oracle.hex(oracle.root(want, threads=64))
+    import json
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_roots.json")))["config5"]
+    assert golden["generator"] == "rndm 42 16777216 4096" and total_bytes == golden["bytes"] and root == golden["root"]
 
 
 def test_one_string_of_512_mib_plus_5_bytes(gpu, oracle):

@@ -205,6 +205,10 @@ def test_the_shipped_library_is_covered_by_the_issue_model(native):
     assert rec["audit"]["unclassified"] == [], rec["audit"]["unclassified"]
     assert rec["audit"]["block_count_errors"] == [], rec["audit"]["block_count_errors"]
     assert "verify" in rec["verified"]
+    # every hash block of a kernel the pass works on got its priority toggles: the pass tracks a kernel's own s_setprio (the map
+    # prologue's) in textual order, and a hash block laid out inside such a region would silently run unpaired
+    from vk_merkle_roots_amd.build import LATENCY_BOUND_KERNELS
+    assert [k for k in rec["audit"]["hash_blocks_without_raised_runs"] if not any(s in k for s in LATENCY_BOUND_KERNELS)] == []
     names = " ".join(rec["audit"]["blocks"])
     for kernel in ("reduce_pass_kernel", "reduce_collapse_kernel", "reduce_tail_kernel", "reduce_level_kernel", "map_kernel"):
         assert kernel in names

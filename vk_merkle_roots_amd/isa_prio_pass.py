@@ -274,12 +274,16 @@ def audit(lines):
     COMPLEX_ASSUMED one used more than ASSUMED_PER_BLOCK times in one block; `block_count_errors` every kernel whose number of
     hash blocks is not EXPECTED_HASH_BLOCKS'.  Both must be empty for the static counts to mean what DESIGN.md 3.1 says."""
     hist, unclassified, blocks = {}, [], {}
-    cur, ops, rot = None, {}, 0
+    unraised = []          # hash blocks in which the pass raised nothing (a kernel it was told to skip is expected here; any other is a
+                           # block it took for part of a raised-priority region: its base priority is tracked in textual, not control-flow, order)
+    cur, ops, rot, raised = None, {}, 0, 0
 
     def close():
-        nonlocal ops, rot
+        nonlocal ops, rot, raised
         if cur is not None and rot > 100:
             blocks[cur] = blocks.get(cur, 0) + 1
+            if raised == 0:
+                unraised.append(cur)
             for b, n in ops.items():
                 hist[b] = hist.get(b, 0) + n
                 k = _known(b)
@@ -287,13 +291,15 @@ def audit(lines):
                     unclassified.append(f"{cur}: {b} x{n} (not measured)")
                 elif k == "assumed" and n > ASSUMED_PER_BLOCK:
                     unclassified.append(f"{cur}: {b} x{n} in one hash block (assumed complex, tolerated up to {ASSUMED_PER_BLOCK})")
-        ops, rot = {}, 0
+        ops, rot, raised = {}, 0, 0
     for ln in lines:
         m = re.match(r"^(_Z\w+):", ln)
         if m:
             close()
             cur = m.group(1)
             continue
+        if cur is not None and re.match(r"^\s+s_setprio\s+[12]\b", ln):
+            raised += 1
         if cur is None:
             continue
         if re.match(r"^\.LBB\w+:", ln):
@@ -317,7 +323,8 @@ def audit(lines):
             errors.append(f"{kernel}: {n} hash block(s) in a kernel nobody listed in EXPECTED_HASH_BLOCKS")
         elif n != want:
             errors.append(f"{kernel}: {n} hash block(s), expected {want}")
-    return {"hash_valu": dict(sorted(hist.items())), "unclassified": sorted(set(unclassified)), "blocks": blocks, "block_count_errors": errors}
+    return {"hash_valu": dict(sorted(hist.items())), "unclassified": sorted(set(unclassified)), "blocks": blocks, "block_count_errors": errors,
+            "hash_blocks_without_raised_runs": sorted(set(unraised))}
 
 
 def verify(original, transformed):
