@@ -101,6 +101,8 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
                                meta_dev, count, out, tile, ntiles, (uint32_t)stagger);
             break;
         }
+        case 25: launch_staged(map_kernel<512, 640, 11840, 0>, 512, 640, 11840); break;     // LDS-staged tiles of 640 strings, 53 KiB of LDS: THREE workgroups per CU = 6 wavefronts per SIMD
+        case 26: launch_staged(map_kernel<384, 768, 14336, 0>, 384, 768, 14336); break;     // 6-wavefront workgroups, tiles of 768 (12 groups: two per wavefront), 64 KiB: two per CU
         case 24:   // per-lane loads, two blocks (128 bytes) per trip (map_kernel MODE 5)
             if (tile >= 1024u)
                 hipLaunchKernelGGL((map_kernel<512, 2048, 64, 5, true>), dim3(grid), dim3(512), (size_t)dyn_lds, s, data_dev, data_words, meta_dev, count, out, tile);
