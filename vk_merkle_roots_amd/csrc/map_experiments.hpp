@@ -55,6 +55,8 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
     static const int stagger = [] { const char* e = getenv("VKMR_MAP_STAGGER"); return e ? atoi(e) : 5; }();   // variant 23: s_sleep(127) count of the late half
     if (variant == 0 && fit_pct == 0 && tile_override == 0 && dyn_lds == 0) return false;
 
+    // (max_tile must be a multiple of threads: every lane takes max_tile / threads metadata entries of a tile -- a 640-string tile on
+    // 512 lanes sorts 512 of its strings; and six wavefronts per SIMD with two groups per wavefront would need 212 KiB of LDS)
     auto launch_staged = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
         const uint32_t tile = staged_tile(data_words, count, max_tile, stage_words, fit_pct);
         hipLaunchKernelGGL(kern, dim3(tiles_of(count, tile)), dim3(threads), (size_t)dyn_lds, s, data_dev, data_words, meta_dev, count, out, tile);
@@ -101,8 +103,6 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
                                meta_dev, count, out, tile, ntiles, (uint32_t)stagger);
             break;
         }
-        case 25: launch_staged(map_kernel<512, 640, 11840, 0>, 512, 640, 11840); break;     // LDS-staged tiles of 640 strings, 53 KiB of LDS: THREE workgroups per CU = 6 wavefronts per SIMD
-        case 26: launch_staged(map_kernel<384, 768, 14336, 0>, 384, 768, 14336); break;     // 6-wavefront workgroups, tiles of 768 (12 groups: two per wavefront), 64 KiB: two per CU
         case 24:   // per-lane loads, two blocks (128 bytes) per trip (map_kernel MODE 5)
             if (tile >= 1024u)
                 hipLaunchKernelGGL((map_kernel<512, 2048, 64, 5, true>), dim3(grid), dim3(512), (size_t)dyn_lds, s, data_dev, data_words, meta_dev, count, out, tile);
