@@ -55,8 +55,9 @@ struct Input::Reader {
             for (;;) {
                 if (end == b->data.size()) b->data.resize(b->data.size() * 2);   // a line longer than the block
                 const ssize_t got = read(fd, b->data.data() + end, b->data.size() - end);
-                if (got < 0 && errno == EINTR) continue;
-                if (got < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {   // a non-blocking stdin: wait for it, this is not the end
+                const int err = got < 0 ? errno : 0;   // before anything below can change it
+                if (got < 0 && err == EINTR) continue;
+                if (got < 0 && (err == EAGAIN || err == EWOULDBLOCK)) {   // a non-blocking stdin: wait for it, this is not the end
                     struct pollfd pfd = {fd, POLLIN, 0};
                     (void)poll(&pfd, 1, 1000);
                     std::lock_guard<std::mutex> lock(self->mu);
@@ -66,7 +67,7 @@ struct Input::Reader {
                 if (got <= 0) {
                     if (got < 0) {   // EIO, EBADF ...: the stream ends here, and the caller is told why
                         std::lock_guard<std::mutex> lock(self->mu);
-                        self->error = errno ? errno : EIO;
+                        self->error = err ? err : EIO;
                     }
                     eof = true;
                     break;
