@@ -263,7 +263,7 @@ private:
         if (st == VKMR_OK) m_proof_dev.push_back(std::make_pair(d.dev, sib));
         if (st == VKMR_OK && !m_proof_host) {
             void* h = nullptr;
-            st = vkmr_hip_host_alloc(kMaxProofs * kProofRecord * sizeof(vkmr_digest), &h);   // per proof: leaf + up to 64 levels in the slice + 64 above it
+            st = vkmr_hip_host_alloc(kMaxProofs * kProofRecord * sizeof(vkmr_digest), &h);   // per proof one record: the leaf + its siblings inside the slice (those above arrive in Combine's own buffer)
             m_proof_host = static_cast<vkmr_digest*>(h);
         }
         if (st == VKMR_OK)
