@@ -6,8 +6,8 @@
 //     per workgroup (runs of consecutive tiles put every workgroup's 1 MiB-strided metadata and 4 MiB-strided digests on the
 //     same channels: 7.6 ms against 5.4, profiles/r04_map_persist.txt);
 //   * at the start of tile k's hashing every lane requests its share of tile k+1: its metadata entries (PER x 8 bytes) and
-//     its 16-byte pieces of the packed bytes (NV x 16 bytes) into registers -- 40 VGPRs the hashing does not need at four
-//     wavefronts per SIMD.  Both HBM round trips of map_kernel's prologue (metadata, then the bytes whose extent the metadata
+//     its words of the packed bytes (NW = 35 single words: nine 16-byte tuples held across the hashing find no aligned homes
+//     and are spilled) into registers -- 43 VGPRs the hashing does not need at four wavefronts per SIMD.  Both HBM round trips of map_kernel's prologue (metadata, then the bytes whose extent the metadata
 //     gives) run under ~35 us of hashing;
 //   * the extent of the next tile's bytes is taken from its first and last metadata entries alone (two loads, requested one
 //     tile earlier still), which is exact for a packed batch (every string starts on the word after the one before,
