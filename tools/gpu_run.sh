@@ -11,6 +11,7 @@
 #   e2e [log2...]          `vkmr hip:0 < file` of 2^k strings (default 25 26): printed time and process wall, N runs each, the distribution
 #   frontend               VKMR_TIMING=1 phases, a pipe, hip-api stats and copy/kernel overlap of `vkmr hip:0`
 #   rehearsals             soaks against the oracle; torchrun --nproc 2 (gloo rehearsal; plain N=2 must fail on one GPU); --force-dist (RCCL, one rank)
+#   cumask                 tools/cu_mask_probe.py: where CU-mask bits land, map/reduce on half the CUs with and without neighbours
 #   issue <set>            tools/issue_patterns (python3 tools/gen_issue_patterns.py <set> and a build beforehand)
 #   proofs                 tools/proof_timing.py: a slice reduced with and without proofs written in the pass
 cd ${GRAFT_REPO_ROOT:-.}
@@ -110,6 +111,10 @@ issue)
   ;;
 proofs)
   for k in "26 8" "26 1" "26 16" "23 16"; do set -- $k; timeout -k 10 300 python3 tools/proof_timing.py --log2 $1 --proofs $2; done > $OUT/proof_timing.txt 2>&1; cat $OUT/proof_timing.txt
+  ;;
+cumask)
+  hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/libwhere.so tools/where.hip
+  timeout -k 10 400 python3 tools/cu_mask_probe.py > $OUT/cu_mask_probe.txt 2>&1; tail -14 $OUT/cu_mask_probe.txt
   ;;
 *) echo "unknown task $task"; exit 2;;
 esac
