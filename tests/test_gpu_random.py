@@ -79,7 +79,7 @@ def test_random_map_length_mixes(gpu, oracle):
         assert (got == want).all(), (case, kind, n)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "9", "10", "20", "21", "23", "24"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "9", "10", "20", "21", "23", "24", "26", "27"])
 def test_every_fetch_mode_of_the_map_kernel_is_bit_exact(variant):
     """The map kernel's fetch modes against the oracle on short, long, ragged, unordered and out-of-range inputs --
     whichever mode a launch picks, the digests are the same.  "0" is the product library choosing from the batch alone;

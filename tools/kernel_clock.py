@@ -123,9 +123,19 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--settle", type=int, default=12, help="launches between the stamp buffer's clearing and the launch whose stamps are read")
+    ap.add_argument("--cus-per-engine", type=int, default=0,
+                    help="1..7: run on a stream whose CU mask leaves that many CUs per shader engine (of 8; mask bit i = XCC i %% 8, engine (i / 8) %% 4, "
+                         "alive CU (i / 8) / 4: profiles/r04_cu_mask_probe.txt) -- the kernels' cycles per instruction with the board far from its power cap")
     a = ap.parse_args()
     dev = vk.HipDevice(0)
     L = C.CDLL(STAMPS_LIB)
+    if a.cus_per_engine:
+        words = (C.c_uint32 * 8)(*[sum(1 << k for k in range(32) if 32 * w + k < 32 * a.cus_per_engine) for w in range(8)])
+        masked = C.c_void_p()
+        rc = C.CDLL("libamdhip64.so").hipExtStreamCreateWithCUMask(C.byref(masked), 8, words)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask: {rc}")
+        dev.stream = masked.value          # every launch, event and wait of this tool goes to the device's default stream
     pci = None
     try:
         hip = C.CDLL("libamdhip64.so")
@@ -146,7 +156,7 @@ def main():
     sp, _ = pinned_u64(dev.lib, SLOTS * 8)
     sys.stderr.write("[kernel_clock] %-14s 0x%012x .. 0x%012x (pinned host)\n" % ("stamp copy", sp.value, sp.value + SLOTS * 64))
     sys.stderr.flush()
-    out = {"workload": f"rndm {a.seed} 2^{a.leaves_log2} {a.maxlen}", "library": os.path.relpath(STAMPS_LIB, ROOT),
+    out = {"cus": 32 * a.cus_per_engine if a.cus_per_engine else 256, "workload": f"rndm {a.seed} 2^{a.leaves_log2} {a.maxlen}", "library": os.path.relpath(STAMPS_LIB, ROOT),
            "method": "per-workgroup d(s_memtime)/d(s_memrealtime) x 100 MHz after >= %.1f s of back-to-back launches" % a.seconds,
            "power_cap_W": Hwmon.read(hw.cap, 1e6), "hwmon": hw.base}
     e0, e1 = dev.new_event(), dev.new_event()

@@ -1,6 +1,6 @@
 // map_experiments.hpp -- EXPERIMENTS BUILD ONLY (-DVKMR_EXPERIMENTS: vk_merkle_roots_amd/build.py build_experiments(),
 // build/ab/libexp.so).  The A/B knobs and the non-shipped map_kernel instantiations behind the measurements in
-// profiles/ (r01_map_fetch_modes.txt, r02_map_tile_fill.txt, r02_long_strings_*.txt, r03_map_lds_schedule_ab.txt).
+// profiles/ (r01_map_fetch_modes.txt, r02_map_tile_fill.txt, r02_long_strings_*.txt, r03_map_lds_schedule_ab.txt, r04_map_cycles_vs_power.txt).
 // The product library is built without this file: its vkmr_hip_map_async picks the mode from the batch alone.
 //   VKMR_MAP_VARIANT  which alternative (below); 0/unset = the shipped choice
 //   VKMR_MAP_FIT      staged tiles: percent of the staging area to fill on average (50..100) instead of the 3-sigma rule
@@ -55,8 +55,8 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
     static const int stagger = [] { const char* e = getenv("VKMR_MAP_STAGGER"); return e ? atoi(e) : 5; }();   // variant 23: s_sleep(127) count of the late half
     if (variant == 0 && fit_pct == 0 && tile_override == 0 && dyn_lds == 0) return false;
 
-    // (max_tile must be a multiple of threads: every lane takes max_tile / threads metadata entries of a tile -- a 640-string tile on
-    // 512 lanes sorts 512 of its strings; and six wavefronts per SIMD with two groups per wavefront would need 212 KiB of LDS)
+    // (a lane takes ceil(max_tile / threads) metadata entries of a tile, so 640-string tiles on 512 lanes and 1024-string tiles on 768 work:
+    // variants 26 and 27, six wavefronts per SIMD -- profiles/r04_map_cycles_vs_power.txt)
     auto launch_staged = [&](auto kern, uint32_t threads, uint32_t max_tile, uint32_t stage_words) {
         const uint32_t tile = staged_tile(data_words, count, max_tile, stage_words, fit_pct);
         hipLaunchKernelGGL(kern, dim3(tiles_of(count, tile)), dim3(threads), (size_t)dyn_lds, s, data_dev, data_words, meta_dev, count, out, tile);
@@ -96,6 +96,8 @@ static bool vkmr_map_experiment(hipStream_t s, const uint32_t* data_dev, uint64_
         case 11: launch_staged(map_kernel<512, 1024, 17600, 0, false, 0>, 512, 1024, 17600); break;  // control for 9/10: same staging, shipped compression
         case 12: launch_staged(map_kernel<1024, 1024, 17664, 0>, 1024, 1024, 17664); break;  // 16 wavefronts per tile: two workgroups = 8 wavefronts per SIMD
         case 13: launch_staged(map_kernel<1024, 2048, 34816, 0>, 1024, 2048, 34816); break;  // one 1024-lane workgroup per CU, 136 KiB tiles of 2048 strings
+        case 26: launch_staged(map_kernel<512, 640, 11072, 0>, 512, 640, 11072); break;      // 640-string tiles of 51 KiB: THREE 8-wavefront workgroups per CU, 6 per SIMD
+        case 27: launch_staged(map_kernel<768, 1024, 17664, 0>, 768, 1024, 17664); break;    // the shipped tile by 12 wavefronts: two workgroups = 6 per SIMD
         case 23: {   // persistent workgroups, the next tile in flight while this one is hashed (map_persist.hpp)
             const uint32_t tile = staged_tile(data_words, count, 1024, 17664, fit_pct), ntiles = tiles_of(count, tile);
             const uint32_t per_cu = dyn_lds ? 1u : 2u, want = (uint32_t)vkmr_exp_cus() * per_cu;

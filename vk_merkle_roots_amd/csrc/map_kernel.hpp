@@ -150,7 +150,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 1) void map_kernel(c
     __syncthreads();
 
     // ---- 1. metadata, keys, extent of the tile's packed bytes -------------------------
-    constexpr int PER = VKMR_MAP_MAX_TILE / VKMR_MAP_THREADS;
+    constexpr int PER = (VKMR_MAP_MAX_TILE + VKMR_MAP_THREADS - 1) / VKMR_MAP_THREADS;
     uint32_t key[PER], rank[PER];
     uint2 mdv[PER];
     unsigned long long lo = ~0ull, hi = 0ull;
