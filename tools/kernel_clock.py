@@ -48,6 +48,14 @@ class Hwmon:
         self.power = _first(base + "power1_average") or _first(base + "power1_input")
         self.cap = _first(base + "power1_cap")
         self.sclk = _first(base + "freq1_input")
+        self.temps = {}                       # label -> path: junction / edge / memory temperatures where the driver shows them
+        for t in sorted(glob.glob(base + "temp*_input")):
+            label = t.replace("_input", "_label")
+            try:
+                with open(label) as f:
+                    self.temps[f.read().strip()] = t
+            except OSError:
+                self.temps[os.path.basename(t)] = t
 
     @staticmethod
     def read(path, scale):
@@ -61,6 +69,7 @@ class Hwmon:
 def sustained(dev, launch, seconds, hw):
     """`seconds` of back-to-back launches with hwmon sampled from a side thread; returns (ms per launch, power W, sclk MHz)."""
     stop, pw, sk = threading.Event(), [], []
+    hw.last_temps = {}
 
     def sample():
         while not stop.is_set():
@@ -69,6 +78,10 @@ def sustained(dev, launch, seconds, hw):
                 pw.append(p)
             if s:
                 sk.append(s)
+            for label, path in hw.temps.items():
+                t = Hwmon.read(path, 1e3)
+                if t is not None:
+                    hw.last_temps.setdefault(label, []).append(t)
             time.sleep(0.02)
 
     t = threading.Thread(target=sample)
@@ -98,10 +111,12 @@ def pinned_u64(lib, words):
     return _PINNED[words]
 
 
-def read_stamps(L, lib, tag):
-    p, view = pinned_u64(lib, SLOTS * 8)
-    assert L.vkmr_hip_debug_stamps(p, SLOTS * 8) == 0
-    s = view.copy().reshape(SLOTS, 8)
+def read_stamps(L, lib, tag, raw=None):
+    if raw is None:
+        p, view = pinned_u64(lib, SLOTS * 8)
+        assert L.vkmr_hip_debug_stamps(p, SLOTS * 8) == 0      # (the read clears the buffer: a second kernel's stamps come from the same copy, `raw`)
+        raw = view.copy().reshape(SLOTS, 8)
+    s = raw
     s = s[((s[:, 6] & np.uint64(0xFFFFFF)) == tag) & (s[:, 5] > s[:, 1])]
     if len(s):
         s = s[s[:, 7] == s[:, 7].max()]      # the widest launch of that kernel (bulk pass 0), not the later, smaller ones
@@ -123,6 +138,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--settle", type=int, default=12, help="launches between the stamp buffer's clearing and the launch whose stamps are read")
+    ap.add_argument("--alternate", action="store_true",
+                    help="one sustained loop of map, reduce, map, reduce ... (the bench's step) instead of one loop per kernel: the clock each kernel "
+                         "holds when it runs behind the other one")
     ap.add_argument("--cus-per-engine", type=int, default=0,
                     help="1..7: run on a stream whose CU mask leaves that many CUs per shader engine (of 8; mask bit i = XCC i %% 8, engine (i / 8) %% 4, "
                          "alive CU (i / 8) / 4: profiles/r04_cu_mask_probe.txt) -- the kernels' cycles per instruction with the board far from its power cap")
@@ -172,6 +190,8 @@ def main():
         dev.record(e0); launch(); dev.record(e1); dev.sync()
         s = read_stamps(L, dev.lib, tag)
         rec = clock_of(s)
+        if hw.last_temps:
+            rec["temperature_C_last_half_second"] = {k: round(float(np.median(v[-25:])), 1) for k, v in hw.last_temps.items()}
         rec.update(ms_per_launch_sustained=round(ms_sus, 4), ms_stamped_launch=round(dev.elapsed_ms(e0, e1), 4),
                    board_power_W=pw, sclk_sysfs_MHz=sk, kernel=dev.lib.vkmr_hip_kernel_info().decode().split(" reduce=")[0] if tag == 0x4d4150 else "reduce_pass_kernel (first bulk pass)")
         if tag == 0x4d4150 and len(s):   # phases of a map workgroup's first wavefront
@@ -184,8 +204,35 @@ def main():
                                   "hash": round(float(np.median((s[:, 4] - s[:, 3]) / life)), 4)}
         out[name] = rec
 
-    one("map_kernel", 0x4d4150, lambda: dev.map_async(d_data, b.words, d_meta, b.count, d_out))
-    one("reduce_pass_kernel", 0x524544, lambda: dev.reduce_async(d_out, b.count, height, d_scr, d_root))
+    def do_map():
+        dev.map_async(d_data, b.words, d_meta, b.count, d_out)
+
+    def do_reduce():
+        dev.reduce_async(d_out, b.count, height, d_scr, d_root)
+
+    if a.alternate:
+        def step():
+            do_map(); do_reduce()
+        ms_sus, pw, sk = sustained(dev, step, a.seconds, hw)
+        L.vkmr_hip_debug_stamps(None, 0)
+        for _ in range(a.settle):
+            step()
+        e2 = dev.new_event()
+        dev.record(e0); do_map(); dev.record(e1); do_reduce(); dev.record(e2); dev.sync()
+        out["alternating"] = {"ms_per_step_sustained": round(ms_sus, 4), "board_power_W": pw, "sclk_sysfs_MHz": sk,
+                              "temperature_C_last_half_second": {k: round(float(np.median(v[-25:])), 1) for k, v in hw.last_temps.items()},
+                              "temperature_C_first_samples": {k: round(float(np.median(v[:3])), 1) for k, v in hw.last_temps.items()},
+                              "map_ms_stamped_step": round(dev.elapsed_ms(e0, e1), 4), "reduce_ms_stamped_step": round(dev.elapsed_ms(e1, e2), 4)}
+        p, view = pinned_u64(dev.lib, SLOTS * 8)
+        assert L.vkmr_hip_debug_stamps(p, SLOTS * 8) == 0
+        raw = view.copy().reshape(SLOTS, 8)
+        for name, tag in (("map_kernel", 0x4d4150), ("reduce_pass_kernel", 0x524544)):
+            out[name] = clock_of(read_stamps(L, dev.lib, tag, raw))
+        out["map_kernel"]["kernel"] = dev.lib.vkmr_hip_kernel_info().decode().split(" reduce=")[0]
+        print(json.dumps(out))
+        return
+    one("map_kernel", 0x4d4150, do_map)
+    one("reduce_pass_kernel", 0x524544, do_reduce)
     print(json.dumps(out))
 
 
